@@ -1,0 +1,175 @@
+"""Generate golden fixtures by RUNNING the reference (build container only).
+
+    cd /root/repo && PYTHONPATH=/root/reference:/root/repo PYTHONDONTWRITEBYTECODE=1 \
+        python tests/golden/make_golden.py
+
+Imports the reference's `style.model` unmodified from /root/reference, drives
+it exactly like train-model.py:52-90,113-126,151-154 does (same construction
+order, seed, Adam/StepLR settings, positional get_total_loss call including the
+bpm-before-mode quirk) on the synthetic clips of oracle/synth.py, and stores
+inputs' seeds + expected outputs as .npz under tests/golden/.  The fixtures are
+data only; nothing of the reference's source travels.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+import style.model as ref                    # the REFERENCE (PYTHONPATH=/root/reference)
+from oracle.synth import synth_clip, INSTRUMENT_SIZE, N_INSTRUMENTS
+
+assert os.path.realpath(ref.__file__).startswith('/root/reference/'), ref.__file__
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+FULL = dict(beat=64, bar=128, nrf=8, style=256, melody=8, rhythm=32)
+SMALL = dict(beat=8, bar=6, nrf=3, style=12, melody=4, rhythm=6)
+
+
+def build(w, seed=108):
+    torch.manual_seed(seed)                  # train-model.py:52
+    pce = ref.PitchedChannelsEncoder(w['beat'], w['bar'], INSTRUMENT_SIZE)
+    uce = ref.UnpitchedChannelsEncoder(w['beat'], w['bar'])
+    pre = ref.PitchedRhythmEncoder(w['rhythm'], w['beat'], w['bar'], INSTRUMENT_SIZE)
+    ure = ref.UnpitchedRhythmEncoder(w['rhythm'], w['beat'], w['bar'])
+    se = ref.StyleEncoder(w['style'], w['bar'], INSTRUMENT_SIZE)
+    me = ref.MelodyEncoder(w['melody'], w['beat'], w['bar'], INSTRUMENT_SIZE)
+    sim = ref.SongInfoModel(w['nrf'], w['style'], w['rhythm'], N_INSTRUMENTS)
+    psa = ref.PitchedStyleApplier(w['style'], w['melody'], w['rhythm'], INSTRUMENT_SIZE)
+    usa = ref.UnpitchedStyleApplier(w['style'], w['rhythm'])
+    return ref.StyleTransferModel(pce, uce, se, me, pre, ure, sim, psa, usa)
+
+
+def flat_losses(d, prefix=''):
+    out = {}
+    for k, v in d.items():
+        if v is None:
+            continue
+        if isinstance(v, dict):
+            out.update(flat_losses(v, prefix + k + '_'))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def iteration(model, clip, capture=None):
+    """One train-model.py loop body up to loss.backward() (train-model.py:113-126)."""
+    hooks = []
+    if capture is not None:
+        def mk(name):
+            def hook(_m, _i, o):
+                o = o if isinstance(o, tuple) else (o,)
+                for j, t in enumerate(o):
+                    capture[f'mid/{name}/{j}'] = t.detach().numpy().copy()
+            return hook
+        for name, mod in model.named_children():
+            hooks.append(mod.register_forward_hook(mk(name)))
+    (ip, mp, bp), xp, xu = model(clip['mode'], clip['bpm'], clip['pitched'],
+                                 clip['instruments_features'], clip['unpitched'])
+    for h in hooks:
+        h.remove()
+    losses = ref.get_total_loss(
+        ip, clip['used_instruments'],
+        bp, clip['bpm_int'],
+        mp, clip['mode'],
+        xp, clip['pitched'],
+        xu, clip['unpitched'],
+        normalize=True,
+    )
+    losses['total'].backward()
+    if capture is not None:
+        capture['out/instruments'] = ip.detach().numpy().copy()
+        capture['out/mode'] = mp.detach().numpy().copy()
+        capture['out/bpm'] = bp.detach().numpy().copy()
+        capture['out/pitched'] = xp.detach().numpy().copy()
+        if xu is not None:
+            capture['out/unpitched'] = xu.detach().numpy().copy()
+    return flat_losses(losses)
+
+
+def fingerprint(t):
+    x = t.detach().double().reshape(-1)
+    return np.array([x.sum(), x.abs().sum(), (x * x).sum(), x[0], x[-1]], dtype=np.float64)
+
+
+def small_case(name, unpitched):
+    C, R, T = 2, 3, 2
+    model = build(SMALL, seed=7)
+    opt = torch.optim.Adam(model.parameters(), lr=.01)           # train-model.py:89
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=200, gamma=.9)
+    out = dict(widths=np.array([SMALL[k] for k in ('beat', 'bar', 'nrf', 'style', 'melody', 'rhythm')]),
+               crt=np.array([C, R, T]), unpitched=np.array(int(unpitched)), density=np.array(0.05))
+    for n, p in model.named_parameters():
+        out['p0/' + n] = p.detach().numpy().copy()
+    opt.zero_grad()
+    l0 = iteration(model, synth_clip(0, C, R, T, unpitched, density=0.05), capture=out)
+    for n, p in model.named_parameters():
+        out['g0/' + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    l1 = iteration(model, synth_clip(1, C, R, T, unpitched, density=0.05))
+    opt.step(); opt.zero_grad(); sched.step()                    # train-model.py:151-154
+    for n, p in model.named_parameters():
+        out['p1/' + n] = p.detach().numpy().copy()
+    for k, v in l0.items():
+        out['loss0/' + k] = np.array(v)
+    for k, v in l1.items():
+        out['loss1/' + k] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'total0', l0['total'], 'total1', l1['total'], len(out), 'arrays')
+
+
+def full_case():
+    """Seed-108 full-width model (train-model.py:52-85) on a 2x2x4 clip: fingerprints only."""
+    C, R, T = 2, 2, 4
+    model = build(FULL)
+    out = dict(crt=np.array([C, R, T]))
+    out['n_params'] = np.array(sum(p.numel() for p in model.parameters()))
+    for n, p in model.named_parameters():
+        out['pf/' + n] = fingerprint(p)
+    cap = {}
+    l0 = iteration(model, synth_clip(3, C, R, T, True), capture=cap)
+    for k, v in cap.items():
+        out['f/' + k] = fingerprint(torch.from_numpy(v))
+    out['out/instruments'] = cap['out/instruments']
+    out['out/mode'] = cap['out/mode']
+    out['out/bpm'] = cap['out/bpm']
+    out['mid/style'] = cap['mid/style_encoder/0']
+    out['slice/pitched'] = cap['out/pitched'][0, 1, 1, 2]        # (10,56,5)
+    out['slice/unpitched'] = cap['out/unpitched'][0, 0, 1, 2]
+    for n, p in model.named_parameters():
+        out['gf/' + n] = fingerprint(p.grad)
+    for k, v in l0.items():
+        out['loss0/' + k] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, 'full_seed108.npz'), **out)
+    print('full', l0['total'], int(out['n_params']))
+
+
+def trajectory_case():
+    """6 iterations / 3 Adam steps on the bench clip shape (C=4,R=16,T=4), clips k=0..5."""
+    C, R, T = 4, 16, 4
+    model = build(FULL)
+    opt = torch.optim.Adam(model.parameters(), lr=.01)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=200, gamma=.9)
+    opt.zero_grad()
+    out = dict(crt=np.array([C, R, T]))
+    keys = None
+    rows = []
+    for it in range(6):
+        l = iteration(model, synth_clip(it, C, R, T, True))
+        keys = keys or sorted(l)
+        rows.append([l[k] for k in keys])
+        if (it + 1) % 2 == 0:
+            opt.step(); opt.zero_grad(); sched.step()
+    out['loss_keys'] = np.array(keys)
+    out['losses'] = np.array(rows, dtype=np.float64)
+    for n, p in model.named_parameters():
+        out['pf/' + n] = fingerprint(p)
+    np.savez_compressed(os.path.join(HERE, 'trajectory_seed108.npz'), **out)
+    print('traj totals', out['losses'][:, keys.index('total')])
+
+
+if __name__ == '__main__':
+    small_case('small_unpitched', True)
+    small_case('small_pitched_only', False)
+    full_case()
+    trajectory_case()
