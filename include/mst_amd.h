@@ -1,0 +1,135 @@
+/* mst_amd.h — C ABI of libmst_amd.so, the MI355X (gfx950) hot path of music-style-transfer.
+ *
+ * The reference (marcinp7/music-style-transfer) is pure Python and has no FFI; the boundary
+ * this library sits behind is the Python surface of style/model.py.  Each entry point names
+ * the reference interface it replaces (paths relative to the reference root).  A maintainer
+ * binds these with ctypes; no torch types cross the boundary — only raw
+ * device pointers, sizes and a hipStream_t.
+ *
+ * Conventions: every function returns 0 on success and a negative mst_status otherwise and
+ * never throws; all work is enqueued on `stream` (no host synchronisation, no allocation in
+ * the launch path — graph-capturable); all tensors are fp32, contiguous, device-resident.
+ */
+#ifndef MST_AMD_H
+#define MST_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MST_OK = 0,
+    MST_ERR_ARG = -1,          /* null pointer / bad size */
+    MST_ERR_UNSUPPORTED = -2,  /* layer width outside the instantiated kernels */
+    MST_ERR_LAUNCH = -3,       /* hipGetLastError() after a launch */
+    MST_ERR_ALLOC = -4,
+} mst_status;
+
+/* Layer widths = the constructor arguments at train-model.py:54-60 + style/data.py:19-31,
+ * clip shape = (channel, bar, beat) of prepare_input's tensors (style/data.py:130-156). */
+typedef struct {
+    int32_t C, R, T;            /* pitched channels, bars, beats per bar (batch is always 1) */
+    int32_t beat, bar, nrf;     /* beat_size, bar_size, n_rhythm_features */
+    int32_t style, melody, rhythm;
+    int32_t instr;              /* instrument_size (51) */
+    int32_t n_instruments;      /* 41 */
+    int32_t has_unpitched;      /* unpitched_channels is not None */
+} mst_dims;
+
+enum { MST_STAGE_EXTRACT = 1, MST_STAGE_INFO = 2, MST_STAGE_APPLY = 4, MST_STAGE_ALL = 7 };
+
+/* Loss leaves, in the key order of get_total_loss's nested dict flattened with '_'
+ * (style/model.py:944-996, train-model.py:148). Unpitched leaves are NaN when absent. */
+enum {
+    MST_L_TOTAL = 0,
+    MST_L_CH_TOTAL, MST_L_P_TOTAL, MST_L_P_NOTES, MST_L_P_VELOCITY, MST_L_P_DURATION, MST_L_P_ACCIDENTALS,
+    MST_L_U_TOTAL, MST_L_U_NOTES, MST_L_U_VELOCITY, MST_L_U_DURATION,
+    MST_L_SI_TOTAL, MST_L_SI_INSTRUMENTS, MST_L_SI_MODE, MST_L_SI_BPM,
+    MST_N_LOSSES
+};
+
+typedef struct mst_plan mst_plan;
+typedef void* mst_stream;       /* hipStream_t */
+
+/* ---- parameter layout: replaces model.parameters()/state_dict() ordering
+ * (style/model.py:36-75,102-126,144-177,203-250,301-344,384-416,446-511,582-622,678-701,727-749).
+ * All parameters live in ONE flat fp32 buffer in model.parameters() order. */
+int32_t mst_param_count(const mst_dims* d);
+int64_t mst_param_floats(const mst_dims* d);
+/* i-th tensor: state_dict name, flat offset, shape (up to 3 dims). */
+int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int32_t name_cap,
+                       int64_t* offset, int32_t* ndim, int32_t shape[3]);
+
+/* ---- plan: static launch schedule + device-side descriptors for one mst_dims. */
+mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);
+void mst_plan_destroy(mst_plan* p);
+int64_t mst_plan_workspace_floats(const mst_plan* p);
+/* Named tensor inside the workspace: activation offset, gradient offset, element count.
+ * Names: "instr","mode","bpm","style","melody","rhythm","instruments_pred","mode_pred",
+ * "bpm_pred","pitched_pred","unpitched_pred","pitched_beats","pitched_bars",... */
+int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t* off, int64_t* goff, int64_t* numel);
+int32_t mst_plan_launch_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
+
+/* ---- forward: StyleTransferModel.extract_style / predict_song_info / apply_style / forward
+ * (style/model.py:751-793), selected by stage_mask. `pitched` (1,C,R,T,10,56,5) and
+ * `unpitched` (1,1,R,T,10,47,2) are borrowed for the call; small inputs and stage-boundary
+ * tensors are read from / written to their workspace slots (mst_plan_tensor). */
+int32_t mst_forward(const mst_plan* p, int32_t stage_mask, const float* params, float* ws,
+                    const float* pitched, const float* unpitched, mst_stream stream);
+
+/* ---- backward of the same stages (what loss.backward() does, train-model.py:126).
+ * Reads output gradients from the workspace gradient slots, accumulates parameter gradients
+ * into gparams (+=, sum semantics — train-model.py:126,151-153). zero_first: clear the
+ * stage's internal gradient slots before running (boundary slots are cleared by the caller
+ * through mst_zero_grads). */
+int32_t mst_backward(const mst_plan* p, int32_t stage_mask, const float* params, float* gparams,
+                     float* ws, const float* pitched, const float* unpitched, mst_stream stream);
+int32_t mst_zero_grads(const mst_plan* p, int32_t stage_mask, float* ws, mst_stream stream);
+
+/* ---- get_total_loss (style/model.py:935-997) with normalize flag; pointer based so that it
+ * also serves the stand-alone Python get_total_loss. n_*_pos = number of note positions
+ * (product of all dims but the last). losses: MST_N_LOSSES floats. saved: MST_LOSS_SAVED floats
+ * carried to the backward call. partials: scratch of mst_loss_scratch_floats(). */
+#define MST_LOSS_SAVED 512
+int64_t mst_loss_scratch_floats(void);
+int32_t mst_total_loss_fwd(const float* pitched_pred, const float* pitched_target, int64_t n_pitched_pos,
+                           const float* unpitched_pred, const float* unpitched_target, int64_t n_unpitched_pos,
+                           const float* instr_logits, const float* instr_target, int32_t n_instr,
+                           const float* mode_logits, const float* mode_target,
+                           const float* bpm_pred, const float* bpm_target,
+                           int32_t normalize, float* losses, float* saved, float* scratch, mst_stream stream);
+/* grad_losses: MST_N_LOSSES upstream gradients (one-hot on MST_L_TOTAL for loss.backward()).
+ * Writes (=) the gradients of every prediction. */
+int32_t mst_total_loss_bwd(const float* pitched_pred, const float* pitched_target, int64_t n_pitched_pos,
+                           const float* unpitched_pred, const float* unpitched_target, int64_t n_unpitched_pos,
+                           const float* instr_logits, const float* instr_target, int32_t n_instr,
+                           const float* mode_logits, const float* mode_target,
+                           const float* bpm_pred, const float* bpm_target,
+                           const float* saved, const float* grad_losses,
+                           float* g_pitched, float* g_unpitched, float* g_instr, float* g_mode, float* g_bpm,
+                           mst_stream stream);
+
+/* ---- one train-model.py loop body (train-model.py:113-126): forward, total loss,
+ * backward; gradients accumulate in gparams. Targets are the inputs (auto-encoder), the
+ * instrument target is `used` (n_instruments), bpm target a device float. losses may be null. */
+int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
+                            const float* pitched, const float* unpitched, float* losses, mst_stream stream);
+
+/* ---- torch.optim.Adam(lr=.01) + StepLR(200,.9) + zero_grad (train-model.py:89-90,151-154)
+ * over the flat buffers. state: 4 floats {step count t, lr_t/(1-b1^t), sqrt(1-b2^t), reserved} kept on the device so that
+ * the launch is graph-replayable; lr = lr0 * gamma^(t / step_size). */
+int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      float* state, double lr0, double beta1, double beta2, double eps,
+                      int32_t step_size, double gamma, int32_t zero_grad, mst_stream stream);
+
+/* ---- hard_output (style/model.py:818-832): n_pos positions x nfeat (5 or 2) features.
+ * Like the reference it also zeroes sub-threshold velocities of `x` in place. */
+int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_stream stream);
+
+const char* mst_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,389 @@
+// get_total_loss (style/model.py:847-997), Adam+StepLR (train-model.py:89-90,151-154) and
+// hard_output (style/model.py:818-832) for gfx950.
+//
+// Loss = one streaming reduction over predictions/targets (7 partial sums per note tensor,
+// HBM-bound, coalesced, per-workgroup partials re-summed in order), a single-lane scalar tail
+// that evaluates the reference's loss tree on a tiny Wengert tape — so every data-dependent
+// Python branch of the reference (safe_div, safe_sqrt) is taken on the device with identical
+// values AND gradients, with no host sync — and one elementwise backward pass.  The tape
+// yields the full Jacobian d(leaf)/d(partial sum), so any loss leaf can be differentiated.
+#include "mst_common.h"
+
+#define LOSS_MAXBLK 256
+#define NP_SUMS 7            // TP FP FN SEvel SEdur BCE Nmask
+#define N_TAPE_IN 16         // 7 pitched + 6 unpitched + instruments, mode, bpm raw losses
+#define SAVED_J 0            // saved[k*16 + j] = d leaf_k / d input_j
+#define EPS_DIV 1e-7f
+
+int64_t mst_loss_scratch_floats(void) { return 2 * LOSS_MAXBLK * 8 + 64; }
+
+// ------------------------------------------------------------------ streaming partial sums
+template <int NFEAT>
+__device__ __forceinline__ void note_terms(const float* p, const float* t, float* acc) {
+    const float pv = p[1], tv = t[1];
+    const float m = tv > 0.f ? 1.f : 0.f;
+    acc[0] += fminf(pv, tv);
+    acc[1] += fmaxf(pv - tv, 0.f);
+    acc[2] += fmaxf(tv - pv, 0.f);
+    const float dv = tv - pv;
+    acc[3] += dv * dv * m;
+    const float dd = (p[0] - fminf(t[0], 6.f)) / 6.f;
+    acc[4] += dd * dd * m;
+    if (NFEAT == 5) {
+        float bce = 0.f;
+#pragma unroll
+        for (int a = 2; a < 5; ++a) {   // F.binary_cross_entropy clamps both logs at -100
+            const float lp = fmaxf(logf(p[a]), -100.f), lq = fmaxf(logf(1.f - p[a]), -100.f);
+            bce -= t[a] * lp + (1.f - t[a]) * lq;
+        }
+        acc[5] += bce * m;
+    }
+    acc[6] += m;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid (nblk_p + nblk_u): first nblk_p workgroups reduce the pitched tensor, the rest the unpitched
+__global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, const float* pt, int64_t np, int nblk_p,
+                                                            const float* up, const float* ut, int64_t nu, int nblk_u,
+                                                            float* scratch) {
+    __shared__ float red[4][NP_SUMS];
+    const bool pitched = (int)blockIdx.x < nblk_p;
+    const int blk = pitched ? blockIdx.x : blockIdx.x - nblk_p;
+    const int nb = pitched ? nblk_p : nblk_u;
+    const int64_t n = pitched ? np : nu;
+    float acc[NP_SUMS];
+#pragma unroll
+    for (int k = 0; k < NP_SUMS; ++k) acc[k] = 0.f;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        if (pitched) note_terms<5>(pp + i * 5, pt + i * 5, acc);
+        else note_terms<2>(up + i * 2, ut + i * 2, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < NP_SUMS; ++k) acc[k] = wave_sum(acc[k]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NP_SUMS; ++k) red[wv][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NP_SUMS) {
+        const int k = threadIdx.x;
+        float* dst = scratch + (pitched ? 0 : LOSS_MAXBLK * 8);
+        dst[blk * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+// ------------------------------------------------------------------ scalar tail on a Wengert tape
+struct Tape {
+    float val[128], da[128], db[128];
+    short ia[128], ib[128];
+    int n;
+    __device__ int push(float v, int a, float pa, int b2, float pb) {
+        val[n] = v; ia[n] = (short)a; da[n] = pa; ib[n] = (short)b2; db[n] = pb;
+        return n++;
+    }
+    __device__ int input(float v) { return push(v, -1, 0.f, -1, 0.f); }
+    __device__ int add(int a, int b2) { return push(val[a] + val[b2], a, 1.f, b2, 1.f); }
+    __device__ int mul(int a, int b2) { return push(val[a] * val[b2], a, val[b2], b2, val[a]); }
+    __device__ int cmul(int a, float c) { return push(val[a] * c, a, c, -1, 0.f); }
+    __device__ int one_minus(int a) { return push(1.f - val[a], a, -1.f, -1, 0.f); }
+    __device__ int sqr(int a) { return push(val[a] * val[a], a, 2.f * val[a], -1, 0.f); }
+    __device__ int div(int a, int b2) {
+        const float d = val[b2];
+        return push(val[a] / d, a, 1.f / d, b2, -val[a] / (d * d));
+    }
+    __device__ int safe_div(int a, int b2) {          // style/model.py:854-860
+        float d = val[b2];
+        if (fabsf(d) < EPS_DIV) d = d < 0.f ? d - EPS_DIV : d + EPS_DIV;
+        return push(val[a] / d, a, 1.f / d, b2, -val[a] / (d * d));
+    }
+    __device__ int safe_sqrt(int a) {                 // style/utils/pytorch.py:68-71
+        if (val[a] == 0.f) return push(0.f, a, 0.f, -1, 0.f);
+        const float r = sqrtf(val[a]);
+        return push(r, a, 0.5f / r, -1, 0.f);
+    }
+    __device__ int tanh_(int a) { const float t = tanhf(val[a]); return push(t, a, 1.f - t * t, -1, 0.f); }
+    // quadratic mean with constant weights 1/k (get_mean, style/utils/pytorch.py:74-94)
+    __device__ int qmean2(int a, int b2) { return safe_sqrt(add(cmul(sqr(a), 0.5f), cmul(sqr(b2), 0.5f))); }
+    __device__ int qmean3(int a, int b2, int c) {
+        const float w = (float)(1.0 / 3.0);
+        return safe_sqrt(add(add(cmul(sqr(a), w), cmul(sqr(b2), w)), cmul(sqr(c), w)));
+    }
+};
+
+// channels losses of one note tensor from its partial sums (style/model.py:863-932)
+__device__ void channel_tree(Tape& tp, int base, bool pitched, bool normalize, int* leaf_total, int* leaf_notes,
+                             int* leaf_vel, int* leaf_dur, int* leaf_acc) {
+    const int TP = base, FP = base + 1, FN = base + 2, SEV = base + 3, SED = base + 4;
+    const int BCE = base + 5, NM = pitched ? base + 6 : base + 5;
+    const int prec = tp.safe_div(TP, tp.add(TP, FP));
+    const int rec = tp.safe_div(TP, tp.add(TP, FN));
+    const int f = tp.cmul(tp.safe_div(tp.mul(prec, rec), tp.add(prec, rec)), 2.f);
+    const int notes = tp.one_minus(f);
+    const int vel = tp.div(SEV, NM);
+    const int dur = tp.div(SED, NM);
+    // first learn the right notes, then the right velocities: weights [notes, 1 - notes] are live
+    const int nv = tp.safe_sqrt(tp.add(tp.mul(notes, tp.sqr(notes)), tp.mul(tp.one_minus(notes), tp.sqr(vel))));
+    int total, acc = -1;
+    if (pitched) {
+        acc = tp.div(BCE, tp.cmul(NM, 3.f));
+        if (normalize) acc = tp.tanh_(acc);
+        total = tp.qmean3(dur, acc, nv);
+    } else {
+        total = tp.qmean2(dur, nv);
+    }
+    *leaf_total = total; *leaf_notes = notes; *leaf_vel = vel; *leaf_dur = dur; *leaf_acc = acc;
+}
+
+__global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int nblk_p, int nblk_u, int has_u,
+                                                       const float* il, const float* it, int ni,
+                                                       const float* mlg, const float* mt,
+                                                       const float* bp, const float* bt, int normalize,
+                                                       float* losses, float* saved) {
+    __shared__ float sums[N_TAPE_IN];
+    const int tid = threadIdx.x;
+    if (tid < 14) {
+        // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; the tape takes all 7 for the
+        // pitched tensor (inputs 0..6) and {TP FP FN SEvel SEdur Nmask} for the unpitched (7..12)
+        const bool pitched = tid < 7;
+        const int k = pitched ? tid : tid - 7;
+        const float* src = scratch + (pitched ? 0 : LOSS_MAXBLK * 8);
+        const int nb = pitched ? nblk_p : (has_u ? nblk_u : 0);
+        float s = 0.f;
+        for (int q = 0; q < nb; ++q) s += src[q * 8 + k];
+        if (pitched) sums[k] = s;
+        else if (k < 5) sums[7 + k] = s;
+        else if (k == 6) sums[12] = s;
+    }
+    // instruments: BCE-with-logits, mean over ni (style/model.py:903)
+    float v = 0.f;
+    for (int j = tid; j < ni; j += 64) {
+        const float x = il[j];
+        v += fmaxf(x, 0.f) - x * it[j] + log1pf(expf(-fabsf(x)));
+    }
+    v = wave_sum(v);
+    if (tid == 0) {
+        sums[13] = v / (float)ni;
+        // mode: cross entropy against argmax of the one-hot target (style/model.py:904), 2 classes
+        const int tgt = mt[1] > mt[0] ? 1 : 0;
+        const float mx = fmaxf(mlg[0], mlg[1]);
+        const float lse = mx + logf(expf(mlg[0] - mx) + expf(mlg[1] - mx));
+        sums[14] = lse - mlg[tgt];
+        const float db = (bp[0] - bt[0]) / 150.f;
+        sums[15] = db * db;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    Tape tp;
+    tp.n = 0;
+    for (int j = 0; j < N_TAPE_IN; ++j) tp.input(sums[j]);
+    int leaf[MST_N_LOSSES];
+    for (int k = 0; k < MST_N_LOSSES; ++k) leaf[k] = -1;
+    int dummy;
+    channel_tree(tp, 0, true, normalize != 0, &leaf[MST_L_P_TOTAL], &leaf[MST_L_P_NOTES], &leaf[MST_L_P_VELOCITY],
+                 &leaf[MST_L_P_DURATION], &leaf[MST_L_P_ACCIDENTALS]);
+    if (has_u) {
+        channel_tree(tp, 7, false, normalize != 0, &leaf[MST_L_U_TOTAL], &leaf[MST_L_U_NOTES], &leaf[MST_L_U_VELOCITY],
+                     &leaf[MST_L_U_DURATION], &dummy);
+        leaf[MST_L_CH_TOTAL] = tp.qmean2(leaf[MST_L_P_TOTAL], leaf[MST_L_U_TOTAL]);
+    } else {
+        leaf[MST_L_CH_TOTAL] = leaf[MST_L_P_TOTAL];
+    }
+    int li = 13, lm = 14;
+    if (normalize) { li = tp.tanh_(13); lm = tp.tanh_(14); }
+    leaf[MST_L_SI_INSTRUMENTS] = li;
+    leaf[MST_L_SI_MODE] = lm;
+    leaf[MST_L_SI_BPM] = 15;
+    leaf[MST_L_SI_TOTAL] = tp.qmean3(li, lm, 15);
+    leaf[MST_L_TOTAL] = tp.qmean2(leaf[MST_L_CH_TOTAL], leaf[MST_L_SI_TOTAL]);
+
+    float adj[128];
+    for (int k = 0; k < MST_N_LOSSES; ++k) {
+        if (leaf[k] < 0) {
+            losses[k] = __builtin_nanf("");
+            for (int j = 0; j < N_TAPE_IN; ++j) saved[SAVED_J + k * N_TAPE_IN + j] = 0.f;
+            continue;
+        }
+        losses[k] = tp.val[leaf[k]];
+        for (int q = 0; q < tp.n; ++q) adj[q] = 0.f;
+        adj[leaf[k]] = 1.f;
+        for (int q = tp.n - 1; q >= N_TAPE_IN; --q) {
+            const float a = adj[q];
+            if (a == 0.f) continue;
+            if (tp.ia[q] >= 0) adj[tp.ia[q]] += a * tp.da[q];
+            if (tp.ib[q] >= 0) adj[tp.ib[q]] += a * tp.db[q];
+        }
+        for (int j = 0; j < N_TAPE_IN; ++j) saved[SAVED_J + k * N_TAPE_IN + j] = adj[j];
+    }
+}
+
+// ------------------------------------------------------------------ elementwise backward
+// grid (nblk_p + nblk_u + 1): note-tensor gradients, last workgroup = song-info head gradients
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const float* pt, int64_t np, int nblk_p,
+                                                       const float* up, const float* ut, int64_t nu, int nblk_u,
+                                                       const float* il, const float* it, int ni,
+                                                       const float* mlg, const float* mt, const float* bp, const float* bt,
+                                                       const float* saved, const float* gl,
+                                                       float* gp, float* gu, float* gi, float* gm, float* gb) {
+    __shared__ float coef[N_TAPE_IN];
+    if (threadIdx.x < N_TAPE_IN) {
+        float c = 0.f;
+        for (int k = 0; k < MST_N_LOSSES; ++k) {
+            const float g = gl[k];
+            if (g != 0.f) c += g * saved[SAVED_J + k * N_TAPE_IN + threadIdx.x];
+        }
+        coef[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const int bx = blockIdx.x;
+    if (bx < nblk_p + nblk_u) {
+        const bool pitched = bx < nblk_p;
+        const int blk = pitched ? bx : bx - nblk_p;
+        const int nb = pitched ? nblk_p : nblk_u;
+        const int64_t n = pitched ? np : nu;
+        const int nf = pitched ? 5 : 2;
+        const float* P = pitched ? pp : up;
+        const float* T = pitched ? pt : ut;
+        float* G = pitched ? gp : gu;
+        const float* c = coef + (pitched ? 0 : 7);
+        const float cTP = c[0], cFP = c[1], cFN = c[2], cSEV = c[3], cSED = c[4];
+        const float cBCE = pitched ? c[5] : 0.f;
+        for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+            const float* p = P + i * nf;
+            const float* t = T + i * nf;
+            float* g = G + i * nf;
+            const float pv = p[1], tv = t[1];
+            const float m = tv > 0.f ? 1.f : 0.f;
+            // torch.min splits the gradient on ties; relu'(0) = 0
+            float gv = cTP * (pv < tv ? 1.f : (pv == tv ? 0.5f : 0.f));
+            gv += cFP * (pv - tv > 0.f ? 1.f : 0.f) - cFN * (tv - pv > 0.f ? 1.f : 0.f);
+            gv -= cSEV * 2.f * (tv - pv) * m;
+            g[1] = gv;
+            g[0] = cSED * 2.f * (p[0] - fminf(t[0], 6.f)) * (1.f / 36.f) * m;
+            if (pitched) {
+#pragma unroll
+                for (int a = 2; a < 5; ++a)   // aten binary_cross_entropy_backward
+                    g[a] = cBCE * m * (p[a] - t[a]) / fmaxf((1.f - p[a]) * p[a], 1e-12f);
+            }
+        }
+    } else {
+        const float ci = coef[13], cm = coef[14], cb = coef[15];
+        // d tanh already folded into coef (the tape's inputs are the raw losses)
+        for (int j = threadIdx.x; j < ni; j += 256) gi[j] = ci * (1.f / (1.f + expf(-il[j])) - it[j]) / (float)ni;
+        if (threadIdx.x == 0) {
+            const int tgt = mt[1] > mt[0] ? 1 : 0;
+            const float mx = fmaxf(mlg[0], mlg[1]);
+            const float e0 = expf(mlg[0] - mx), e1 = expf(mlg[1] - mx);
+            gm[0] = cm * (e0 / (e0 + e1) - (tgt == 0 ? 1.f : 0.f));
+            gm[1] = cm * (e1 / (e0 + e1) - (tgt == 1 ? 1.f : 0.f));
+            gb[0] = cb * 2.f * (bp[0] - bt[0]) / (150.f * 150.f);
+        }
+    }
+}
+
+static int blocks_for(int64_t n) {
+    int64_t b = (n + 1023) / 1024;
+    if (b < 1) b = 1;
+    if (b > LOSS_MAXBLK) b = LOSS_MAXBLK;
+    return (int)b;
+}
+
+extern "C" int32_t mst_total_loss_fwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,
+                                      int64_t nu, const float* il, const float* it, int32_t ni, const float* mlg,
+                                      const float* mt, const float* bp, const float* bt, int32_t normalize,
+                                      float* losses, float* saved, float* scratch, mst_stream stream) {
+    if (!pp || !pt || !il || !it || !mlg || !mt || !bp || !bt || !losses || !saved || !scratch || np <= 0)
+        return MST_ERR_ARG;
+    const int has_u = (up && ut && nu > 0) ? 1 : 0;
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(nbp + nbu), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
+                       has_u ? nu : (int64_t)0, nbu, scratch);
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, nbp, nbu, has_u, il, it,
+                       (int)ni, mlg, mt, bp, bt, (int)normalize, losses, saved);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+extern "C" int32_t mst_total_loss_bwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,
+                                      int64_t nu, const float* il, const float* it, int32_t ni, const float* mlg,
+                                      const float* mt, const float* bp, const float* bt, const float* saved,
+                                      const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb,
+                                      mst_stream stream) {
+    if (!pp || !pt || !saved || !gl || !gp || !gi || !gm || !gb || np <= 0) return MST_ERR_ARG;
+    const int has_u = (up && ut && gu && nu > 0) ? 1 : 0;
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nbp + nbu + 1), dim3(256), 0, (hipStream_t)stream, pp, pt, np, nbp, up, ut,
+                       has_u ? nu : (int64_t)0, nbu, il, it, (int)ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ Adam + StepLR
+// state[0] = optimizer steps taken so far (t); the prepare kernel turns it into the step's
+// scalars in double precision exactly as torch's Python-side arithmetic does, then bumps t.
+__global__ void adam_prepare_kernel(float* state, double lr0, double b1, double b2, int step_size, double gamma) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = (int)state[0] + 1;
+    const double lr = lr0 * pow(gamma, (double)((t - 1) / step_size));
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    state[0] = (float)t;
+    state[1] = (float)(lr / bc1);
+    state[2] = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ state,
+                                                   float b1, float b2, float eps, int zero_grad) {
+    const float step = state[1], bc2s = state[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * (mi / (sqrtf(vi) / bc2s + eps));
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+extern "C" int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                 double lr0, double beta1, double beta2, double eps, int32_t step_size, double gamma,
+                                 int32_t zero_grad, mst_stream stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n <= 0 || step_size <= 0) return MST_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, s, state, lr0, beta1, beta2, (int)step_size, gamma);
+    int64_t nb = (n + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                       (const float*)state, (float)beta1, (float)beta2, (float)eps, (int)zero_grad);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ hard_output
+__global__ __launch_bounds__(256) void hard_output_kernel(float* x, float* out, int64_t n, int nf) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float* xi = x + i * nf;
+        float* o = out + i * nf;
+        o[0] = xi[0];
+        const float vel = xi[1] > .01f ? xi[1] : 0.f;   // velocity *= (velocity > .01), in place on the input too
+        xi[1] = vel;
+        o[1] = vel;
+        if (nf > 2) {
+            const float mx = fmaxf(xi[2], fmaxf(xi[3], xi[4]));
+            for (int a = 2; a < 5; ++a) o[a] = (xi[a] == mx && xi[a] > .1f) ? 1.f : 0.f;
+        }
+    }
+}
+
+extern "C" int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_stream stream) {
+    if (!x || !out || n_pos <= 0 || (nfeat != 5 && nfeat != 2)) return MST_ERR_ARG;
+    int64_t nb = (n_pos + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(hard_output_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, n_pos, (int)nfeat);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}

@@ -1,0 +1,151 @@
+// Internal shared definitions: derived layer sizes, device-side descriptors, launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mst_amd.h"
+
+// ---- piano-roll constants (style/model.py:13-25)
+#define NF 10       // beat fractions
+#define NPF 5       // pitched note features
+#define NUF 2       // unpitched note features
+#define NOCT 8
+#define NDEG 7
+#define NPN 56      // pitched notes
+#define NUN 47      // unpitched notes
+#define CONV_K 14
+#define CONV_PAD 4
+#define LEAKY 0.01f
+
+// address spaces a descriptor offset can live in: activations, flat params, flat param grads,
+// the two borrowed note tensors, the gradient arena (mirrors SP_WS offsets), scratch
+enum { SP_WS = 0, SP_PAR = 1, SP_GPAR = 2, SP_EXT0 = 3, SP_EXT1 = 4, SP_GRAD = 5, SP_TMP = 6, SP_COUNT = 7 };
+struct Bases { float* p[SP_COUNT]; };
+
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SIGOUT = 2, ACT_BPM = 3 };
+
+// ---- generic GEMM: C[m,n] = epilogue(sum_k A(m,k) * B(k,n))
+enum { OPK_DENSE = 0, OPK_CAT = 1, OPK_ACTGRAD = 2, OPK_IM2COL = 3, OPK_PERMW = 4, OPK_CONVGRAD = 5 };
+#define MAX_SEG 6
+struct Seg {
+    int32_t space, ld, start, width;
+    int64_t off;
+    int32_t s[4];        // source-row stride for each of the 4 row-space dims (0 = broadcast)
+};
+struct Operand {
+    int32_t kind;
+    int32_t space;       // DENSE / ACTGRAD(dY) / IM2COL(x) / CONVW / CONVGRAD(dY)
+    int64_t off;
+    int64_t si, sj;      // DENSE: val = base[off + i*si + j*sj], (i,j) = (m,k) for A, (k,n) for B
+    int32_t ones_at;     // second index == ones_at -> 1.0f (bias-gradient column); -1 = none
+    int32_t kfast;       // tile loader walks the k index fastest (coalescing hint)
+    // CAT (first index = row in the 4-D row space, second = concatenated feature)
+    int32_t nseg, d1, d2, d3;
+    Seg seg[MAX_SEG];
+    // ACTGRAD: val(row,j) = dY[row*ld+j] * act'(Y[row*ld+j]); transposed: first index is j
+    int32_t space2, ld, act, transposed;
+    int64_t off2;
+    int32_t oc;          // conv: number of output channels
+    int32_t pb, pc;      // PERMW: k = (a, b, c) with sizes (., pb, pc) reads weight column a*pb*pc + c*pb + b
+};
+enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_CONV = 2, OUT_SLAB = 3, OUT_PERMW_SLAB = 4 };
+struct OutSpec {
+    int32_t kind, space, ldc, act;
+    int64_t off;
+    int32_t bias_space;  // -1 = no bias
+    int64_t bias_off;
+    int64_t slab_stride; // OUT_SLAB: floats between k-splits
+    int32_t wcols;       // OUT_SLAB: columns n < wcols are weights (row-major m*wcols+n); n == wcols is the bias column
+    int32_t pb, pc;      // OUT_PERMW_SLAB: same column permutation as OPK_PERMW
+};
+struct GemmDesc {
+    int32_t M, N, K, ksplit;
+    Operand A, B;
+    OutSpec out;
+};
+
+// ---- segment reduce: dX_seg[idx, w] += sum_{rows -> idx} dAcat[row, start + w]
+struct SegRedDesc {
+    int64_t src_off; int32_t src_ld; int32_t start, width;   // dAcat in SP_TMP
+    int64_t dst_off; int32_t dst_ld;                           // gradient slot in SP_GRAD
+    int32_t d[4];        // row-space dims
+    int32_t s[4];        // destination row stride per dim (0 = reduced)
+    int32_t nidx;        // number of distinct destination rows
+    int32_t kd[4];       // kept-dim sizes (1 where reduced)
+};
+
+// ---- LSTM recurrence
+struct LstmDesc {
+    int32_t B, S, H, reverse;
+    int64_t zx_off;      // (B*S, 4H) input projection incl. b_ih          [SP_WS]
+    int64_t whh_off, bhh_off;                                             // [SP_PAR]
+    int64_t out_off; int32_t out_ld;                                      // h written at out_off + row*out_ld
+    int64_t gates_off, c_off, hprev_off;                                  // saved (B*S,4H),(B*S,H),(B*S,H)
+    int64_t gout_off;    // gradient of out (same ld)                      [SP_WS]
+    int64_t gzx_off;     // gradient of zx, written (=)
+};
+
+// ---- combine (style/model.py:796-815): out = sum_c x_c n_c / sum_c n_c
+#define COMBINE_MAXC 32
+#define COMBINE_MAXBLK 64
+struct CombineDesc {
+    int32_t Cn, rows, cols, ld;  // each slice: rows x cols, row stride ld
+    int64_t x_off, cs;           // slice c at x_off + c*cs                [SP_WS]
+    int64_t out_off;             // rows*cols contiguous
+    int64_t stats_off;           // Cn + 1 floats: n_c..., S  (+ partial scratch behind it)
+    int64_t part_off;            // COMBINE_MAXBLK * (Cn+1) partials
+    int64_t gx_off, gout_off;    // gradient slots (gx has the x layout)
+    int32_t nblk;
+};
+
+// ---- note-level fused stages
+struct NotesDesc {
+    int32_t C, Q;                // channels, R*T
+    int32_t W, CW, ML;           // melody width, channels_linear width, melody_linear width
+    int64_t oct_off, deg_off;    // ME: (P, 8W),(P,7W);  PSA: (P*F, 240),(P*F, 210)
+    int64_t x_off; int32_t x_space;  // ME: pitched input
+    int64_t ml_off;              // PSA: (Q*F*56, ML)
+    int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)
+    int64_t out_off;             // ME: mel_c (P,F,56,W); PSA: (P,F,56,5)
+    int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;
+    int64_t slab_off; int32_t slab_stride; int32_t nblk;
+};
+
+// ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
+struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; };
+
+// ---- derived layer sizes (style/model.py:31-33 and every ctor)
+struct Sizes {
+    // pce
+    int OC, PCE_IL, H, HB;
+    // se
+    int SE_L, SE_IL, SE_ML, SE_BL;
+    // me
+    int ME_BL, ME_BRL, ME_IL, ME_CW, MEL;
+    // pre / ure
+    int RH, PRE_BL, PRE_BRL, PRE_CL, PRE_IL, PRE_ML, PRE_BPL, URE_CL;
+    // sim
+    int SIM_BL, NRF, SIM_SI, SIM_RI, SIM_SM, SIM_RM, SIM_SB, SIM_RB, NI;
+    // psa / usa
+    int PSA_SL, PSA_RL, PSA_IL, PSA_ML, USA_SL, USA_RL;
+    int I, STYLE, BAR;
+};
+Sizes mst_sizes(const mst_dims& d);
+
+// ---- launchers (each returns a hipError_t-style int; 0 = ok)
+int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s);
+int launch_segred(const SegRedDesc* dev_descs, int count, int max_idx, Bases b, hipStream_t s);
+int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
+int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
+int launch_combine_fwd(const CombineDesc* dev_desc, const CombineDesc& host, Bases b, hipStream_t s);
+int launch_combine_bwd(const CombineDesc* dev_desc, const CombineDesc& host, Bases b, hipStream_t s);
+int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
+int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
+int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
+int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
+int launch_slab_reduce(const SlabEntry* dev, int count, int max_count, Bases b, hipStream_t s);
+bool notes_widths_supported(int W, int CW, int ML);
+
+#define GEMM_BM 64
+#define GEMM_BN 64
+#define GEMM_BK 16

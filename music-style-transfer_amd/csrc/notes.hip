@@ -1,0 +1,346 @@
+// Note-level fused stages for gfx950.
+//
+// MelodyEncoder tail (style/model.py:270-296) and PitchedStyleApplier tail (:644-675) share one
+// shape: an "octave (+) scale-degree" outer sum  h[o*7+d] = leaky(oct[o] + deg[d])  per note,
+// concatenated with a small per-note vector and pushed through a tiny Linear.  The reference
+// materialises the (positions x 56 x 50) concat in memory (358 MB at the training cap); here
+// every note is one lane, the octave/degree rows of the position sit in LDS, the tiny weights
+// are LDS-broadcast, and nothing but the final 8 (or 5) outputs per note touches HBM.
+//
+// Backward kernels recompute the cheap per-note activations instead of saving them, stage the
+// per-note gradient vectors of one (position, fraction) in LDS, and then run "role" threads:
+// one lane per weight-gradient element (kept in a register across the workgroup's whole
+// grid-stride loop, one slab row per workgroup at the end) and one lane per octave / degree
+// gradient element (7- or 8-term LDS sums).  No float atomics; summation order is fixed.
+#include "mst_common.h"
+
+__device__ __forceinline__ float lrelu(float z) { return z > 0.f ? z : z * LEAKY; }
+__device__ __forceinline__ float dlrelu(float y) { return y > 0.f ? 1.f : LEAKY; }
+
+// ============================================================================ MelodyEncoder
+template <int W, int CW>
+__global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc& d = *dp;
+    constexpr int KL = W + CW;
+    __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL], bl_s[W];
+    __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
+    const int tid = threadIdx.x;
+    const float* par = b.p[SP_PAR];
+    for (int i = tid; i < CW * NPF; i += 256) wc_s[i] = par[d.wc_off + i];
+    for (int i = tid; i < CW; i += 256) bc_s[i] = par[d.bc_off + i];
+    for (int i = tid; i < W * KL; i += 256) wl_s[i] = par[d.wl_off + i];
+    for (int i = tid; i < W; i += 256) bl_s[i] = par[d.bl_off + i];
+    const float* x = b.p[d.x_space] + d.x_off;
+    float* ws = b.p[SP_WS];
+    const int P = d.C * d.Q;
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < NOCT * W; i += 256) oct_s[i] = ws[d.oct_off + (int64_t)p * NOCT * W + i];
+        for (int i = tid; i < NDEG * W; i += 256) deg_s[i] = ws[d.deg_off + (int64_t)p * NDEG * W + i];
+        __syncthreads();
+        for (int item = tid; item < NF * NPN; item += 256) {
+            const int n = item % NPN, o = n / NDEG, dg = n - o * NDEG;
+            const float* xi = x + ((int64_t)p * NF * NPN + item) * NPF;
+            float x5[NPF];
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) x5[i] = xi[i];
+            float cat[KL];
+#pragma unroll
+            for (int j = 0; j < W; ++j) cat[j] = lrelu(oct_s[o * W + j] + deg_s[dg * W + j]);
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                float z = bc_s[k];
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) z = fmaf(wc_s[k * NPF + i], x5[i], z);
+                cat[W + k] = lrelu(z);
+            }
+            float* out = ws + d.out_off + ((int64_t)p * NF * NPN + item) * W;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                float z = bl_s[j];
+#pragma unroll
+                for (int i = 0; i < KL; ++i) z = fmaf(wl_s[j * KL + i], cat[i], z);
+                out[j] = lrelu(z);
+            }
+        }
+    }
+}
+
+template <int W, int CW>
+__global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc& d = *dp;
+    constexpr int KL = W + CW;
+    constexpr int R_WC = 0, R_BC = CW * NPF, R_WL = R_BC + CW, R_BL = R_WL + W * KL, NW = R_BL + W;
+    static_assert(NW <= 256 && (NOCT + NDEG) * W <= 256, "role count exceeds the workgroup");
+    __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL];
+    __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
+    __shared__ float gm_s[NPN][W], god_s[NPN][W], gc_s[NPN][CW], cat_s[NPN][KL], x_s[NPN][NPF];
+    const int tid = threadIdx.x;
+    const float* par = b.p[SP_PAR];
+    for (int i = tid; i < CW * NPF; i += 256) wc_s[i] = par[d.wc_off + i];
+    for (int i = tid; i < CW; i += 256) bc_s[i] = par[d.bc_off + i];
+    for (int i = tid; i < W * KL; i += 256) wl_s[i] = par[d.wl_off + i];
+    const float* x = b.p[d.x_space] + d.x_off;
+    float* ws = b.p[SP_WS];
+    const int P = d.C * d.Q;
+    float wacc = 0.f;                       // this lane's weight-gradient element
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < NOCT * W; i += 256) oct_s[i] = ws[d.oct_off + (int64_t)p * NOCT * W + i];
+        for (int i = tid; i < NDEG * W; i += 256) deg_s[i] = ws[d.deg_off + (int64_t)p * NDEG * W + i];
+        float odacc = 0.f;                  // this lane's octave / degree gradient element
+        for (int f = 0; f < NF; ++f) {
+            __syncthreads();
+            if (tid < NPN) {
+                const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+                const int64_t pos = (int64_t)p * NF * NPN + f * NPN + n;
+                float cat[KL];
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) x_s[n][i] = x[pos * NPF + i];
+#pragma unroll
+                for (int j = 0; j < W; ++j) cat[j] = lrelu(oct_s[o * W + j] + deg_s[dg * W + j]);
+#pragma unroll
+                for (int k = 0; k < CW; ++k) {
+                    float z = bc_s[k];
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) z = fmaf(wc_s[k * NPF + i], x_s[n][i], z);
+                    cat[W + k] = lrelu(z);
+                }
+                float gm[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    gm[j] = b.p[SP_GRAD][d.g_out_off + pos * W + j] * dlrelu(ws[d.out_off + pos * W + j]);
+                    gm_s[n][j] = gm[j];
+                }
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) g = fmaf(gm[j], wl_s[j * KL + i], g);
+                    g *= dlrelu(cat[i]);
+                    cat_s[n][i] = cat[i];
+                    if (i < W) god_s[n][i] = g; else gc_s[n][i - W] = g;
+                }
+            }
+            __syncthreads();
+            if (tid < NW) {
+                float a = 0.f;
+                if (tid >= R_BL) {
+                    const int j = tid - R_BL;
+                    for (int n = 0; n < NPN; ++n) a += gm_s[n][j];
+                } else if (tid >= R_WL) {
+                    const int j = (tid - R_WL) / KL, i = (tid - R_WL) % KL;
+                    for (int n = 0; n < NPN; ++n) a = fmaf(gm_s[n][j], cat_s[n][i], a);
+                } else if (tid >= R_BC) {
+                    const int k = tid - R_BC;
+                    for (int n = 0; n < NPN; ++n) a += gc_s[n][k];
+                } else {
+                    const int k = tid / NPF, i = tid % NPF;
+                    for (int n = 0; n < NPN; ++n) a = fmaf(gc_s[n][k], x_s[n][i], a);
+                }
+                wacc += a;
+            }
+            if (tid < NOCT * W) {
+                const int o = tid / W, j = tid % W;
+                float a = 0.f;
+#pragma unroll
+                for (int dg = 0; dg < NDEG; ++dg) a += god_s[o * NDEG + dg][j];
+                odacc += a;
+            } else if (tid < (NOCT + NDEG) * W) {
+                const int dg = (tid - NOCT * W) / W, j = tid % W;
+                float a = 0.f;
+#pragma unroll
+                for (int o = 0; o < NOCT; ++o) a += god_s[o * NDEG + dg][j];
+                odacc += a;
+            }
+        }
+        if (tid < NOCT * W) b.p[SP_GRAD][d.g_oct_off + (int64_t)p * NOCT * W + tid] += odacc;
+        else if (tid < (NOCT + NDEG) * W) b.p[SP_GRAD][d.g_deg_off + (int64_t)p * NDEG * W + (tid - NOCT * W)] += odacc;
+    }
+    if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
+}
+
+// ============================================================================ PitchedStyleApplier
+#define PSA_HW 30
+template <int ML>
+__global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc& d = *dp;
+    constexpr int KL = PSA_HW + ML;
+    __shared__ float w_s[NPF * KL], b_s[NPF];
+    __shared__ float lo_s[NOCT * PSA_HW], ld_s[NDEG * PSA_HW];
+    const int tid = threadIdx.x;
+    const float* par = b.p[SP_PAR];
+    for (int i = tid; i < NPF * KL; i += 64) w_s[i] = par[d.wl_off + i];
+    if (tid < NPF) b_s[tid] = par[d.bl_off + tid];
+    float* ws = b.p[SP_WS];
+    const int QF = d.Q * NF;
+    const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+    for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
+        __syncthreads();
+        float zm[NPF];
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) zm[i] = 0.f;
+        if (n < NPN) {
+            const float* ml = ws + d.ml_off + ((int64_t)qf * NPN + n) * ML;
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                float z = b_s[i];
+#pragma unroll
+                for (int k = 0; k < ML; ++k) z = fmaf(w_s[i * KL + PSA_HW + k], ml[k], z);
+                zm[i] = z;
+            }
+        }
+        for (int c = 0; c < d.C; ++c) {
+            const int64_t row = (int64_t)c * QF + qf;
+            __syncthreads();
+            for (int i = tid; i < NOCT * PSA_HW; i += 64) lo_s[i] = ws[d.oct_off + row * (NOCT * PSA_HW) + i];
+            for (int i = tid; i < NDEG * PSA_HW; i += 64) ld_s[i] = ws[d.deg_off + row * (NDEG * PSA_HW) + i];
+            __syncthreads();
+            if (n < NPN) {
+                float z[NPF];
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) z[i] = zm[i];
+#pragma unroll
+                for (int j = 0; j < PSA_HW; ++j) {
+                    const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) z[i] = fmaf(w_s[i * KL + j], h, z[i]);
+                }
+                float* out = ws + d.out_off + (row * NPN + n) * NPF;
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const float s = 1.f / (1.f + expf(-z[i]));
+                    out[i] = i == 0 ? 6.f * s : s;
+                }
+            }
+        }
+    }
+}
+
+template <int ML>
+__global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc& d = *dp;
+    constexpr int KL = PSA_HW + ML;
+    constexpr int NW = NPF * KL + NPF;                 // linear.weight (5 x KL) then linear.bias (5)
+    constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW;
+    static_assert(NW <= 256, "role count exceeds the workgroup");
+    __shared__ float w_s[NPF * KL];
+    __shared__ float lo_s[NLO], ld_s[NLD];
+    __shared__ float dz_s[NPN][NPF], h_s[NPN][PSA_HW], dh_s[NPN][PSA_HW], ml_s[NPN][ML];
+    const int tid = threadIdx.x;
+    const float* par = b.p[SP_PAR];
+    for (int i = tid; i < NPF * KL; i += 256) w_s[i] = par[d.wl_off + i];
+    float* ws = b.p[SP_WS];
+    const int QF = d.Q * NF;
+    const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+    float wacc = 0.f;
+    for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < NPN * ML; i += 256) ml_s[i / ML][i % ML] = ws[d.ml_off + (int64_t)qf * NPN * ML + i];
+        float gml[ML];
+#pragma unroll
+        for (int k = 0; k < ML; ++k) gml[k] = 0.f;
+        for (int c = 0; c < d.C; ++c) {
+            const int64_t row = (int64_t)c * QF + qf;
+            __syncthreads();
+            for (int i = tid; i < NLO; i += 256) lo_s[i] = ws[d.oct_off + row * NLO + i];
+            for (int i = tid; i < NLD; i += 256) ld_s[i] = ws[d.deg_off + row * NLD + i];
+            __syncthreads();
+            if (n < NPN) {
+                const int64_t pos = row * NPN + n;
+                float dz[NPF];
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const float y = ws[d.out_off + pos * NPF + i];
+                    const float dy = b.p[SP_GRAD][d.g_out_off + pos * NPF + i];
+                    dz[i] = dy * (i == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y));
+                    dz_s[n][i] = dz[i];
+                }
+#pragma unroll
+                for (int j = 0; j < PSA_HW; ++j) {
+                    const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
+                    float g = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + j], g);
+                    h_s[n][j] = h;
+                    dh_s[n][j] = g * dlrelu(h);
+                }
+#pragma unroll
+                for (int k = 0; k < ML; ++k) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + PSA_HW + k], g);
+                    gml[k] += g;
+                }
+            }
+            __syncthreads();
+            if (tid < NW) {
+                float a = 0.f;
+                if (tid >= NPF * KL) {
+                    const int i = tid - NPF * KL;
+                    for (int m = 0; m < NPN; ++m) a += dz_s[m][i];
+                } else {
+                    const int i = tid / KL, jj = tid % KL;
+                    if (jj < PSA_HW) { for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], h_s[m][jj], a); }
+                    else { for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], ml_s[m][jj - PSA_HW], a); }
+                }
+                wacc += a;
+            }
+            for (int r = tid; r < NLO + NLD; r += 256) {
+                float a = 0.f;
+                if (r < NLO) {
+                    const int oo = r / PSA_HW, j = r % PSA_HW;
+#pragma unroll
+                    for (int q = 0; q < NDEG; ++q) a += dh_s[oo * NDEG + q][j];
+                    b.p[SP_GRAD][d.g_oct_off + row * NLO + r] += a;
+                } else {
+                    const int q = (r - NLO) / PSA_HW, j = (r - NLO) % PSA_HW;
+#pragma unroll
+                    for (int oo = 0; oo < NOCT; ++oo) a += dh_s[oo * NDEG + q][j];
+                    b.p[SP_GRAD][d.g_deg_off + row * NLD + (r - NLO)] += a;
+                }
+            }
+        }
+        if (n < NPN) {
+            float* g = b.p[SP_GRAD] + d.g_ml_off + ((int64_t)qf * NPN + n) * ML;
+#pragma unroll
+            for (int k = 0; k < ML; ++k) g[k] += gml[k];
+        }
+    }
+    if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
+}
+
+// ============================================================================ dispatch
+bool notes_widths_supported(int W, int CW, int ML) {
+    bool me = (W == 8 && CW == 7) || (W == 4 && CW == 5);
+    bool psa = ML == 20 || ML == 14;
+    return me && psa;
+}
+
+#define ME_DISPATCH(KERN, GRID, BLOCK)                                                              \
+    if (h.W == 8 && h.CW == 7) hipLaunchKernelGGL((KERN<8, 7>), GRID, BLOCK, 0, s, dev, b);           \
+    else if (h.W == 4 && h.CW == 5) hipLaunchKernelGGL((KERN<4, 5>), GRID, BLOCK, 0, s, dev, b);      \
+    else return MST_ERR_UNSUPPORTED;
+#define PSA_DISPATCH(KERN, GRID, BLOCK)                                                             \
+    if (h.ML == 20) hipLaunchKernelGGL((KERN<20>), GRID, BLOCK, 0, s, dev, b);                        \
+    else if (h.ML == 14) hipLaunchKernelGGL((KERN<14>), GRID, BLOCK, 0, s, dev, b);                   \
+    else return MST_ERR_UNSUPPORTED;
+
+int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+    int P = h.C * h.Q;
+    ME_DISPATCH(me_notes_fwd_kernel, dim3(P < 2048 ? P : 2048), dim3(256));
+    return (int)hipGetLastError();
+}
+int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+    ME_DISPATCH(me_notes_bwd_kernel, dim3(h.nblk), dim3(256));
+    return (int)hipGetLastError();
+}
+int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+    int QF = h.Q * NF;
+    PSA_DISPATCH(psa_notes_fwd_kernel, dim3(QF < 4096 ? QF : 4096), dim3(64));
+    return (int)hipGetLastError();
+}
+int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+    PSA_DISPATCH(psa_notes_bwd_kernel, dim3(h.nblk), dim3(256));
+    return (int)hipGetLastError();
+}

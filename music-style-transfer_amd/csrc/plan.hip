@@ -1,0 +1,773 @@
+// Plan builder + C ABI.  A plan is the whole StyleTransferModel (style/model.py:727-793) for one
+// (layer widths, clip shape) unrolled into a static list of ops; every op carries its forward
+// launch steps AND the backward steps that undo it, so loss.backward() is "walk the list in
+// reverse".  All descriptors are uploaded once at plan creation; running a plan only enqueues
+// kernels on the caller's stream (no allocation, no host sync => hipGraph-capturable).
+//
+// Workspace layout (floats):  [ activations | gradients (same offsets) | scratch ]
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mst_common.h"
+
+// ------------------------------------------------------------------------------------------ sizes
+static int mean_size(double a, double b, double factor = 1.0) { return (int)std::ceil(((a + b) / 2.0) * factor); }
+
+Sizes mst_sizes(const mst_dims& d) {
+    Sizes z{};
+    z.I = d.instr; z.STYLE = d.style; z.BAR = d.bar; z.H = d.beat; z.HB = d.bar / 2; z.RH = d.rhythm;
+    z.MEL = d.melody; z.NRF = d.nrf; z.NI = d.n_instruments;
+    z.OC = mean_size(NF * NPF, d.beat);                       // style/model.py:41-42
+    z.PCE_IL = mean_size(d.instr, d.beat);                    // :43
+    z.SE_L = mean_size(d.bar, d.style);                       // :148-151
+    z.SE_IL = mean_size(d.instr, d.style, .25);
+    z.SE_ML = mean_size(2, d.style, .1);
+    z.SE_BL = mean_size(d.style, 1, .05);
+    z.ME_BL = mean_size(d.beat, d.melody);                    // :207-211
+    z.ME_BRL = mean_size(d.bar, d.melody);
+    z.ME_IL = mean_size(d.instr, d.melody, .25);
+    z.ME_CW = mean_size(NPF, d.melody);
+    z.PRE_BL = mean_size(d.beat, d.rhythm);                   // :305-311
+    z.PRE_BRL = mean_size(d.bar, d.rhythm, .5);
+    z.PRE_CL = mean_size(NPN * NPF, d.rhythm, .1);
+    z.PRE_IL = mean_size(d.instr, d.rhythm, .5);
+    z.PRE_ML = mean_size(2, d.rhythm, .25);
+    z.PRE_BPL = mean_size(1, d.rhythm, .25);
+    z.URE_CL = mean_size(NUN * NUF, d.rhythm, .25);           // :390-391
+    z.SIM_BL = mean_size(NF * d.rhythm, d.nrf, .05);          // :450-460
+    z.SIM_SI = mean_size(d.style, d.n_instruments, .05);
+    z.SIM_RI = mean_size(d.rhythm, d.n_instruments, .25);
+    z.SIM_SM = mean_size(d.style, 2, .01);
+    z.SIM_RM = mean_size(d.rhythm, 2, .1);
+    z.SIM_SB = mean_size(d.style, 1, .01);
+    z.SIM_RB = mean_size(d.rhythm, 1, .1);
+    z.PSA_SL = mean_size(d.style, NPF, .5);                   // :586-590
+    z.PSA_RL = mean_size(d.rhythm, NPF, .5);
+    z.PSA_IL = mean_size(d.instr, NPF, .4);
+    z.PSA_ML = mean_size(d.melody, NPF, 3);
+    z.USA_SL = mean_size(d.style, NUF, .5);                   // :682-684
+    z.USA_RL = mean_size(d.rhythm, NUF, 1);
+    return z;
+}
+
+// ------------------------------------------------------------------------------------------ params
+struct PInfo { std::string name; int64_t off, numel; int ndim; int shape[3]; };
+
+struct ParamTable {
+    std::vector<PInfo> v;
+    std::map<std::string, int> idx;
+    int64_t top = 0;
+    void add(const std::string& name, int a, int b = 0, int c = 0) {
+        PInfo p; p.name = name; p.off = top; p.ndim = 1 + (b > 0) + (c > 0);
+        p.shape[0] = a; p.shape[1] = b; p.shape[2] = c;
+        p.numel = (int64_t)a * (b > 0 ? b : 1) * (c > 0 ? c : 1);
+        top += p.numel;
+        idx[name] = (int)v.size();
+        v.push_back(p);
+    }
+    void lin(const std::string& pre, int out, int in) { add(pre + ".weight", out, in); add(pre + ".bias", out); }
+    void lstm(const std::string& pre, int in, int hid, bool bi) {
+        for (int r = 0; r < (bi ? 2 : 1); ++r) {
+            const std::string sfx = r ? "_reverse" : "";
+            add(pre + ".weight_ih_l0" + sfx, 4 * hid, in);
+            add(pre + ".weight_hh_l0" + sfx, 4 * hid, hid);
+            add(pre + ".bias_ih_l0" + sfx, 4 * hid);
+            add(pre + ".bias_hh_l0" + sfx, 4 * hid);
+        }
+    }
+    int64_t off(const std::string& name) const {
+        auto it = idx.find(name);
+        if (it == idx.end()) { fprintf(stderr, "mst: unknown parameter %s\n", name.c_str()); abort(); }
+        return v[it->second].off;
+    }
+};
+
+// registration order == model.parameters() order (style/model.py:737-749 and each ctor)
+static void build_params(const mst_dims& d, const Sizes& z, ParamTable& t) {
+    std::string m = "pitched_channels_encoder";
+    t.add(m + ".beats_conv.module.weight", z.OC, NF * NPF, CONV_K);
+    t.add(m + ".beats_conv.module.bias", z.OC);
+    t.lin(m + ".instruments_linear", z.PCE_IL, z.I);
+    t.lin(m + ".linear", z.H, z.OC * NOCT + z.PCE_IL);
+    t.lstm(m + ".beats_lstm.module", z.H, z.H, false);
+    t.lstm(m + ".bars_lstm", z.H, z.HB, true);
+    m = "unpitched_channels_encoder";
+    t.lin(m + ".linear", z.H, NF * NUN * NUF);
+    t.lstm(m + ".beats_lstm.module", z.H, z.H, false);
+    t.lstm(m + ".bars_lstm", z.H, z.HB, true);
+    m = "style_encoder";
+    t.lstm(m + ".bars_lstm", z.BAR, z.SE_L, false);
+    t.lin(m + ".instruments_linear", z.SE_IL, z.I);
+    t.lin(m + ".mode_linear", z.SE_ML, 2);
+    t.lin(m + ".bpm_linear", z.SE_BL, 1);
+    t.lin(m + ".linear", z.STYLE, z.SE_L + z.SE_IL + z.SE_ML + z.SE_BL);
+    m = "melody_encoder";
+    t.lin(m + ".beats_linear", z.ME_BL, z.H);
+    t.lin(m + ".bars_linear", z.ME_BRL, z.BAR);
+    t.lin(m + ".instruments_linear", z.ME_IL, z.I);
+    t.lin(m + ".octave_linear", z.MEL * NOCT, z.ME_BL + z.ME_BRL + z.ME_IL);
+    t.lin(m + ".scale_degree_linear", z.MEL * NDEG, z.ME_BL + z.ME_BRL + z.ME_IL);
+    t.lin(m + ".channels_linear", z.ME_CW, NPF);
+    t.lin(m + ".linear", z.MEL, z.MEL + z.ME_CW);
+    m = "pitched_rhythm_encoder";
+    t.lin(m + ".beats_linear", z.PRE_BL, z.H);
+    t.lin(m + ".bars_linear", z.PRE_BRL, z.BAR);
+    t.lin(m + ".channels_linear", z.PRE_CL, NPN * NPF);
+    t.lin(m + ".instruments_linear", z.PRE_IL, z.I);
+    t.lin(m + ".mode_linear", z.PRE_ML, 2);
+    t.lin(m + ".bpm_linear", z.PRE_BPL, 1);
+    t.lin(m + ".linear", z.RH, z.PRE_BL + z.PRE_BRL + z.PRE_CL + z.PRE_IL + z.PRE_ML + z.PRE_BPL);
+    m = "unpitched_rhythm_encoder";
+    t.lin(m + ".beats_linear", z.PRE_BL, z.H);
+    t.lin(m + ".bars_linear", z.PRE_BRL, z.BAR);
+    t.lin(m + ".channels_linear", z.URE_CL, NUN * NUF);
+    t.lin(m + ".bpm_linear", z.PRE_BPL, 1);
+    t.lin(m + ".linear", z.RH, z.PRE_BL + z.PRE_BRL + z.URE_CL + z.PRE_BPL);
+    m = "song_info_model";
+    t.lstm(m + ".beats_lstm.module", NF * z.RH, z.SIM_BL, false);
+    t.lstm(m + ".bars_lstm", z.SIM_BL, z.NRF, false);
+    t.lin(m + ".style_instruments_linear", z.SIM_SI, z.STYLE);
+    t.lin(m + ".rhythm_instruments_linear", z.SIM_RI, z.NRF);
+    t.lin(m + ".instruments_linear", z.NI, z.SIM_SI + z.SIM_RI);
+    t.lin(m + ".style_mode_linear", z.SIM_SM, z.STYLE);
+    t.lin(m + ".rhythm_mode_linear", z.SIM_RM, z.NRF);
+    t.lin(m + ".mode_linear", 2, z.SIM_SM + z.SIM_RM);
+    t.lin(m + ".style_bpm_linear", z.SIM_SB, z.STYLE);
+    t.lin(m + ".rhythm_bpm_linear", z.SIM_RB, z.NRF);
+    t.lin(m + ".bpm_linear", 1, z.SIM_SB + z.SIM_RB);
+    m = "pitched_style_applier";
+    t.lin(m + ".style_linear", z.PSA_SL, z.STYLE);
+    t.lin(m + ".rhythm_linear", z.PSA_RL, z.RH);
+    t.lin(m + ".instruments_linear", z.PSA_IL, z.I);
+    t.lin(m + ".octave_linear", NPF * 6 * NOCT, z.PSA_SL + z.PSA_RL + z.PSA_IL);
+    t.lin(m + ".scale_degree_linear", NPF * 6 * NDEG, z.PSA_SL + z.PSA_RL + z.PSA_IL);
+    t.lin(m + ".melody_linear", z.PSA_ML, z.MEL);
+    t.lin(m + ".linear", NPF, NPF * 6 + z.PSA_ML);
+    m = "unpitched_style_applier";
+    t.lin(m + ".style_linear", NF * z.USA_SL, z.STYLE);
+    t.lin(m + ".rhythm_linear", z.USA_RL, z.RH);
+    t.lin(m + ".notes_linear", NUN * NUF * 4, z.USA_SL + z.USA_RL);
+    t.lin(m + ".linear", NUF, NUF * 4);
+}
+
+static bool dims_ok(const mst_dims* d) {
+    return d && d->C >= 1 && d->C <= COMBINE_MAXC && d->R >= 1 && d->T >= 1 && d->beat >= 1 && d->bar >= 2 &&
+           d->bar % 2 == 0 && d->nrf >= 1 && d->style >= 1 && d->melody >= 1 && d->rhythm >= 1 && d->instr >= 1 &&
+           d->n_instruments >= 1;
+}
+
+extern "C" int32_t mst_param_count(const mst_dims* d) {
+    if (!dims_ok(d)) return MST_ERR_ARG;
+    ParamTable t; build_params(*d, mst_sizes(*d), t);
+    return (int32_t)t.v.size();
+}
+extern "C" int64_t mst_param_floats(const mst_dims* d) {
+    if (!dims_ok(d)) return MST_ERR_ARG;
+    ParamTable t; build_params(*d, mst_sizes(*d), t);
+    return t.top;
+}
+extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int32_t cap, int64_t* off, int32_t* ndim,
+                                  int32_t shape[3]) {
+    if (!dims_ok(d) || !name || !off || !ndim || !shape) return MST_ERR_ARG;
+    ParamTable t; build_params(*d, mst_sizes(*d), t);
+    if (i < 0 || i >= (int)t.v.size()) return MST_ERR_ARG;
+    const PInfo& p = t.v[i];
+    snprintf(name, cap, "%s", p.name.c_str());
+    *off = p.off; *ndim = p.ndim;
+    for (int k = 0; k < 3; ++k) shape[k] = p.shape[k];
+    return MST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ plan
+struct T { int64_t off; int rows, cols, ld; };
+struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
+enum { K_GEMM, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B };
+struct Step { int kind, first, count, a, b; };
+struct Op { int stage; std::vector<Step> fwd, bwd; };
+
+static int stage_idx(int stage) { return stage == MST_STAGE_EXTRACT ? 0 : stage == MST_STAGE_INFO ? 1 : 2; }
+
+struct mst_plan {
+    mst_dims d; Sizes z; ParamTable pt;
+    std::vector<GemmDesc> gemms; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
+    std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<SlabEntry> slabs[3];
+    std::vector<Op> ops;
+    std::map<std::string, T> named;
+    int64_t act_top = 0, tmp_top = 0;
+    int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
+    GemmDesc* d_gemms = nullptr; SegRedDesc* d_segreds = nullptr; LstmDesc* d_lstms = nullptr;
+    CombineDesc* d_combines = nullptr; NotesDesc* d_notes = nullptr; SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
+    int slab_max[3] = {0, 0, 0};
+    T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
+    int err = 0;
+
+    int P() const { return d.C * d.R * d.T; }
+    int Q() const { return d.R * d.T; }
+
+    static int64_t align(int64_t n) { return (n + 63) / 64 * 64; }
+    T newT(int rows, int cols, const char* name = nullptr) {
+        T t{act_top, rows, cols, cols};
+        act_top += align((int64_t)rows * cols);
+        if (name) named[name] = t;
+        return t;
+    }
+    int64_t tmp(int64_t n) { int64_t o = tmp_top; tmp_top += align(n); return o; }
+    static int tiles(int M, int N) { return ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN); }
+    static int splits_for(int K) { int s = K / 256; return s < 1 ? 1 : (s > 128 ? 128 : s); }
+
+    static SegIn seg(const T& t, int s0, int s1, int s2, int s3, bool grad = true) {
+        return SegIn{SP_WS, t.off, t.ld, t.cols, {s0, s1, s2, s3}, grad};
+    }
+    static SegIn segx(int space, int ld, int width, int s0, int s1, int s2, int s3) {
+        return SegIn{space, 0, ld, width, {s0, s1, s2, s3}, false};
+    }
+
+    void fill_cat(Operand& o, const int rs[4], const std::vector<SegIn>& segs, int ones_at, int kfast) {
+        o.kind = OPK_CAT; o.nseg = (int)segs.size(); o.d1 = rs[1]; o.d2 = rs[2]; o.d3 = rs[3];
+        o.ones_at = ones_at; o.kfast = kfast;
+        int start = 0;
+        for (size_t i = 0; i < segs.size(); ++i) {
+            Seg& s = o.seg[i];
+            s.space = segs[i].space; s.off = segs[i].off; s.ld = segs[i].ld; s.start = start; s.width = segs[i].width;
+            for (int q = 0; q < 4; ++q) s.s[q] = segs[i].s[q];
+            start += segs[i].width;
+        }
+    }
+
+    // cat_with_broadcast + nn.Linear (+ activation); emits forward GEMM, weight-gradient GEMM (k-split
+    // slabs) and, when any source needs a gradient, the input-gradient GEMM + per-source reductions.
+    T linear(int stage, const int rs[4], const std::vector<SegIn>& segs, const std::string& wname,
+             const std::string& bname, int N, int act, const T* out_opt = nullptr, int pb = 0, int pc = 0,
+             const char* name = nullptr) {
+        if (segs.size() > MAX_SEG) { err = MST_ERR_UNSUPPORTED; }
+        const int rows = rs[0] * rs[1] * rs[2] * rs[3];
+        int K = 0;
+        for (auto& s : segs) K += s.width;
+        T out = out_opt ? *out_opt : newT(rows, N, name);
+        const int64_t woff = pt.off(wname), boff = pt.off(bname);
+        Op op; op.stage = stage;
+        {
+            GemmDesc g{}; g.M = rows; g.N = N; g.K = K; g.ksplit = 1;
+            fill_cat(g.A, rs, segs, -1, 1);
+            if (pb) { g.B.kind = OPK_PERMW; g.B.space = SP_PAR; g.B.off = woff; g.B.ld = K; g.B.pb = pb; g.B.pc = pc; g.B.kfast = 1; }
+            else { g.B.kind = OPK_DENSE; g.B.space = SP_PAR; g.B.off = woff; g.B.si = 1; g.B.sj = K; g.B.ones_at = -1; g.B.kfast = 1; }
+            g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = act; g.out.off = out.off;
+            g.out.bias_space = SP_PAR; g.out.bias_off = boff;
+            op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
+            gemms.push_back(g);
+        }
+        {   // dW | db
+            GemmDesc w{}; w.M = N; w.N = K + 1; w.K = rows; w.ksplit = splits_for(rows);
+            w.A.kind = OPK_ACTGRAD; w.A.space = SP_GRAD; w.A.off = out.off; w.A.space2 = SP_WS; w.A.off2 = out.off;
+            w.A.ld = out.ld; w.A.act = act; w.A.transposed = 1; w.A.kfast = 0;
+            fill_cat(w.B, rs, segs, K, 0);
+            const int64_t stride = (int64_t)N * K + N;
+            const int64_t slab = tmp(stride * w.ksplit);
+            w.out.kind = pb ? OUT_PERMW_SLAB : OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride;
+            w.out.wcols = K; w.out.pb = pb; w.out.pc = pc; w.out.bias_space = -1;
+            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(N, K + 1), w.ksplit});
+            gemms.push_back(w);
+            slabs[stage_idx(stage)].push_back(SlabEntry{woff, slab, stride, N * K, w.ksplit});
+            slabs[stage_idx(stage)].push_back(SlabEntry{boff, slab + (int64_t)N * K, stride, N, w.ksplit});
+        }
+        bool any_grad = false;
+        for (auto& s : segs) any_grad |= s.grad;
+        if (any_grad) {
+            if (pb) { err = MST_ERR_UNSUPPORTED; }
+            // one source whose rows are exactly the output rows: accumulate straight into its gradient
+            bool single = segs.size() == 1;
+            if (single) {
+                int nat = 1;
+                for (int q = 3; q >= 0; --q) {
+                    if (rs[q] > 1 && segs[0].s[q] != nat) single = false;
+                    nat *= rs[q];
+                }
+            }
+            GemmDesc a{}; a.M = rows; a.N = K; a.K = N; a.ksplit = 1;
+            a.A.kind = OPK_ACTGRAD; a.A.space = SP_GRAD; a.A.off = out.off; a.A.space2 = SP_WS; a.A.off2 = out.off;
+            a.A.ld = out.ld; a.A.act = act; a.A.transposed = 0; a.A.kfast = 1;
+            a.B.kind = OPK_DENSE; a.B.space = SP_PAR; a.B.off = woff; a.B.si = K; a.B.sj = 1; a.B.ones_at = -1; a.B.kfast = 0;
+            a.out.bias_space = -1; a.out.act = ACT_NONE;
+            if (single) {
+                a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = segs[0].off; a.out.ldc = segs[0].ld;
+                op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
+                gemms.push_back(a);
+            } else {
+                const int64_t dacat = tmp((int64_t)rows * K);
+                a.out.kind = OUT_STORE; a.out.space = SP_TMP; a.out.off = dacat; a.out.ldc = K;
+                op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
+                gemms.push_back(a);
+                int first = (int)segreds.size(), cnt = 0, maxidx = 1, start = 0;
+                for (auto& s : segs) {
+                    if (s.grad) {
+                        SegRedDesc r{}; r.src_off = dacat; r.src_ld = K; r.start = start; r.width = s.width;
+                        r.dst_off = s.off; r.dst_ld = s.ld; r.nidx = 1;
+                        for (int q = 0; q < 4; ++q) {
+                            r.d[q] = rs[q]; r.s[q] = s.s[q];
+                            r.kd[q] = (s.s[q] != 0 && rs[q] > 1) ? rs[q] : 1;
+                            r.nidx *= r.kd[q];
+                        }
+                        // destination rows must be the natural row-major index of the kept dims
+                        int nat = 1;
+                        for (int q = 3; q >= 0; --q) {
+                            if (r.kd[q] > 1) { if (s.s[q] != nat) err = MST_ERR_UNSUPPORTED; nat *= r.kd[q]; }
+                        }
+                        if (r.nidx > maxidx) maxidx = r.nidx;
+                        segreds.push_back(r); ++cnt;
+                    }
+                    start += s.width;
+                }
+                op.bwd.push_back(Step{K_SEGRED, first, cnt, maxidx, 0});
+            }
+        }
+        ops.push_back(op);
+        return out;
+    }
+
+    // Conv1d(50 -> OC, k=14, s=7, p=4) over the note axis + leaky, as implicit-im2col GEMM (style/model.py:46-53,78-84)
+    T conv(int stage) {
+        const int P_ = P();
+        T x1 = newT(P_, z.OC * NOCT, "pce_conv");
+        const int64_t woff = pt.off("pitched_channels_encoder.beats_conv.module.weight");
+        const int64_t boff = pt.off("pitched_channels_encoder.beats_conv.module.bias");
+        const int K = NF * NPF * CONV_K;
+        Op op; op.stage = stage;
+        GemmDesc g{}; g.M = P_ * NOCT; g.N = z.OC; g.K = K; g.ksplit = 1;
+        g.A.kind = OPK_IM2COL; g.A.space = SP_EXT0; g.A.off = 0; g.A.ones_at = -1; g.A.kfast = 1;
+        g.B.kind = OPK_PERMW; g.B.space = SP_PAR; g.B.off = woff; g.B.ld = K; g.B.pb = CONV_K; g.B.pc = NPF; g.B.kfast = 1;
+        g.out.kind = OUT_CONV; g.out.space = SP_WS; g.out.off = x1.off; g.out.ldc = z.OC * NOCT;
+        g.out.bias_space = SP_PAR; g.out.bias_off = boff;
+        op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(g.M, g.N), 1});
+        gemms.push_back(g);
+        GemmDesc w{}; w.M = z.OC; w.N = K + 1; w.K = P_ * NOCT; w.ksplit = splits_for(w.K);
+        w.A.kind = OPK_CONVGRAD; w.A.space = SP_GRAD; w.A.off = x1.off; w.A.space2 = SP_WS; w.A.off2 = x1.off;
+        w.A.oc = z.OC; w.A.kfast = 1;
+        w.B.kind = OPK_IM2COL; w.B.space = SP_EXT0; w.B.off = 0; w.B.ones_at = K; w.B.kfast = 0;
+        const int64_t stride = (int64_t)z.OC * K + z.OC;
+        const int64_t slab = tmp(stride * w.ksplit);
+        w.out.kind = OUT_PERMW_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = K;
+        w.out.pb = CONV_K; w.out.pc = NPF; w.out.bias_space = -1;
+        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
+        gemms.push_back(w);
+        slabs[stage_idx(stage)].push_back(SlabEntry{woff, slab, stride, z.OC * K, w.ksplit});
+        slabs[stage_idx(stage)].push_back(SlabEntry{boff, slab + (int64_t)z.OC * K, stride, z.OC, w.ksplit});
+        ops.push_back(op);
+        return x1;
+    }
+
+    // one LSTM direction: input projection (a linear op) + the recurrence op
+    void lstm(int stage, const int rs[4], const std::vector<SegIn>& xsegs, int B, int S, int H, int reverse,
+              const std::string& pre, const T& out, int coloff) {
+        const std::string sfx = reverse ? "_reverse" : "";
+        T zx = linear(stage, rs, xsegs, pre + ".weight_ih_l0" + sfx, pre + ".bias_ih_l0" + sfx, 4 * H, ACT_NONE);
+        if (4 * H > 1024) err = MST_ERR_UNSUPPORTED;
+        const int64_t whh = pt.off(pre + ".weight_hh_l0" + sfx), bhh = pt.off(pre + ".bias_hh_l0" + sfx);
+        const int64_t n = (int64_t)B * S;
+        Op op; op.stage = stage;
+        LstmDesc l{}; l.B = B; l.S = S; l.H = H; l.reverse = reverse; l.zx_off = zx.off; l.whh_off = whh; l.bhh_off = bhh;
+        l.out_off = out.off + coloff; l.out_ld = out.ld;
+        l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H);
+        l.gout_off = out.off + coloff; l.gzx_off = zx.off;
+        op.fwd.push_back(Step{K_LSTM_F, (int)lstms.size(), 1, B, H});
+        op.bwd.push_back(Step{K_LSTM_B, (int)lstms.size(), 1, B, H});
+        lstms.push_back(l);
+        GemmDesc w{}; w.M = 4 * H; w.N = H + 1; w.K = (int)n; w.ksplit = splits_for((int)n);
+        w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = zx.off; w.A.si = 1; w.A.sj = 4 * H; w.A.ones_at = -1; w.A.kfast = 0;
+        w.B.kind = OPK_DENSE; w.B.space = SP_TMP; w.B.off = l.hprev_off; w.B.si = H; w.B.sj = 1; w.B.ones_at = H; w.B.kfast = 0;
+        const int64_t stride = (int64_t)4 * H * H + 4 * H;
+        const int64_t slab = tmp(stride * w.ksplit);
+        w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = H;
+        w.out.bias_space = -1;
+        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
+        gemms.push_back(w);
+        slabs[stage_idx(stage)].push_back(SlabEntry{whh, slab, stride, 4 * H * H, w.ksplit});
+        slabs[stage_idx(stage)].push_back(SlabEntry{bhh, slab + (int64_t)4 * H * H, stride, 4 * H, w.ksplit});
+        ops.push_back(op);
+    }
+
+    void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out) {
+        CombineDesc c{}; c.Cn = Cn; c.rows = rows; c.cols = cols; c.ld = ld; c.x_off = x_off; c.cs = cs; c.out_off = out.off;
+        c.stats_off = tmp(64); c.part_off = tmp(COMBINE_MAXBLK * (COMBINE_MAXC + 1));
+        c.gx_off = x_off; c.gout_off = out.off;
+        int64_t nb = ((int64_t)rows * cols + 1023) / 1024;
+        c.nblk = (int)(nb < 1 ? 1 : (nb > COMBINE_MAXBLK ? COMBINE_MAXBLK : nb));
+        Op op; op.stage = stage;
+        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, 0, 0});
+        combines.push_back(c);
+        ops.push_back(op);
+    }
+
+    void build();
+    int upload();
+};
+
+static const int RS1[4] = {1, 1, 1, 1};
+
+void mst_plan::build() {
+    const int C = d.C, R = d.R, Tn = d.T, P_ = P(), Q_ = Q();
+    const bool U = d.has_unpitched != 0;
+    const int E = MST_STAGE_EXTRACT, IN = MST_STAGE_INFO, AP = MST_STAGE_APPLY;
+    // ---- inputs / targets (never zeroed, written by the host side)
+    T instr = newT(C, z.I, "instr"), mode = newT(1, 2, "mode"), bpm = newT(1, 1, "bpm");
+    newT(1, z.NI, "used_instruments"); newT(1, 1, "bpm_target");
+    t_losses = newT(1, 64, "losses"); t_saved = newT(1, MST_LOSS_SAVED, "loss_saved"); t_gl = newT(1, 64, "grad_losses");
+    loss_scratch = tmp(mst_loss_scratch_floats());
+    auto segI = [&](const T& t) { SegIn s = seg(t, 1, 0, 0, 0, false); return s; };      // per-channel input row
+    auto seg0 = [&](const T& t, bool grad) { return seg(t, 0, 0, 0, 0, grad); };          // global (broadcast) row
+    auto rows1 = [&](int n) { return std::vector<int>{n, 1, 1, 1}; };
+    (void)rows1;
+
+    // ================================================================= stage 1: extract_style
+    stage_begin[0] = act_top;
+    std::string m = "pitched_channels_encoder";
+    const int rsC[4] = {C, 1, 1, 1}, rsP[4] = {P_, 1, 1, 1}, rsR[4] = {R, 1, 1, 1}, rsQ[4] = {Q_, 1, 1, 1};
+    T pce_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PCE_IL, ACT_LEAKY);
+    T x1 = conv(E);
+    const int rsCQ[4] = {C, R * Tn, 1, 1};
+    T pa = linear(E, rsCQ, {seg(x1, R * Tn, 1, 0, 0), seg(pce_il, 1, 0, 0, 0)}, m + ".linear.weight", m + ".linear.bias", z.H, ACT_LEAKY);
+    T pbeats = newT(P_, z.H, "pitched_beats");
+    lstm(E, rsP, {seg(pa, 1, 0, 0, 0)}, C * R, Tn, z.H, 0, m + ".beats_lstm.module", pbeats, 0);
+    T plast = newT(R, z.H);
+    combine(E, pbeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, (int64_t)R * Tn * z.H, C, plast);
+    T pbars = newT(R, 2 * z.HB, "pitched_bars");
+    lstm(E, rsR, {seg(plast, 1, 0, 0, 0)}, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0);
+    lstm(E, rsR, {seg(plast, 1, 0, 0, 0)}, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB);
+
+    m = "pitched_rhythm_encoder";
+    T pre_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PRE_IL, ACT_LEAKY);
+    T pre_ml = linear(E, RS1, {seg0(mode, false)}, m + ".mode_linear.weight", m + ".mode_linear.bias", z.PRE_ML, ACT_LEAKY);
+    T pre_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.PRE_BPL, ACT_LEAKY);
+    T pre_bl = linear(E, rsP, {seg(pbeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.PRE_BL, ACT_LEAKY);
+    T pre_br = linear(E, rsR, {seg(pbars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.PRE_BRL, ACT_LEAKY);
+    const int rsPF[4] = {P_ * NF, 1, 1, 1};
+    T pre_cl = linear(E, rsPF, {segx(SP_EXT0, NPN * NPF, NPN * NPF, 1, 0, 0, 0)}, m + ".channels_linear.weight",
+                      m + ".channels_linear.bias", z.PRE_CL, ACT_LEAKY);
+    const int rsCRTF[4] = {C, R, Tn, NF};
+    T prh_c = linear(E, rsCRTF,
+                     {seg(pre_bl, R * Tn, Tn, 1, 0), seg(pre_br, 0, 1, 0, 0), seg(pre_cl, R * Tn * NF, Tn * NF, NF, 1),
+                      seg(pre_il, 1, 0, 0, 0), seg0(pre_ml, true), seg0(pre_bp, true)},
+                     m + ".linear.weight", m + ".linear.bias", z.RH, ACT_LEAKY);
+    T prh = newT(Q_ * NF, z.RH, "pitched_rhythm");
+    combine(E, prh_c.off, Q_ * NF, z.RH, z.RH, (int64_t)Q_ * NF * z.RH, C, prh);
+
+    T bars = pbars, rhythm = prh;
+    if (U) {
+        m = "unpitched_channels_encoder";
+        T ua = linear(E, rsQ, {segx(SP_EXT1, NF * NUN * NUF, NF * NUN * NUF, 1, 0, 0, 0)}, m + ".linear.weight",
+                      m + ".linear.bias", z.H, ACT_LEAKY, nullptr, NUN, NUF);
+        T ubeats = newT(Q_, z.H, "unpitched_beats");
+        lstm(E, rsQ, {seg(ua, 1, 0, 0, 0)}, R, Tn, z.H, 0, m + ".beats_lstm.module", ubeats, 0);
+        T ulast = newT(R, z.H);
+        combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
+        T ubars = newT(R, 2 * z.HB, "unpitched_bars");
+        lstm(E, rsR, {seg(ulast, 1, 0, 0, 0)}, 1, R, z.HB, 0, m + ".bars_lstm", ubars, 0);
+        lstm(E, rsR, {seg(ulast, 1, 0, 0, 0)}, 1, R, z.HB, 1, m + ".bars_lstm", ubars, z.HB);
+        m = "unpitched_rhythm_encoder";
+        T ure_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.PRE_BPL, ACT_LEAKY);
+        T ure_bl = linear(E, rsQ, {seg(ubeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.PRE_BL, ACT_LEAKY);
+        T ure_br = linear(E, rsR, {seg(ubars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.PRE_BRL, ACT_LEAKY);
+        const int rsQF[4] = {Q_ * NF, 1, 1, 1};
+        T ure_cl = linear(E, rsQF, {segx(SP_EXT1, NUN * NUF, NUN * NUF, 1, 0, 0, 0)}, m + ".channels_linear.weight",
+                          m + ".channels_linear.bias", z.URE_CL, ACT_LEAKY);
+        const int rs1RTF[4] = {1, R, Tn, NF};
+        T urh_c = linear(E, rs1RTF,
+                         {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp, true)},
+                         m + ".linear.weight", m + ".linear.bias", z.RH, ACT_LEAKY);
+        T urh = newT(Q_ * NF, z.RH, "unpitched_rhythm");
+        combine(E, urh_c.off, Q_ * NF, z.RH, z.RH, 0, 1, urh);
+        // combine(pitched, unpitched) stacks the pair on a new leading axis (style/model.py:766-767)
+        bars = newT(R, z.BAR, "bars");
+        combine(E, pbars.off, R, z.BAR, z.BAR, ubars.off - pbars.off, 2, bars);
+        rhythm = newT(Q_ * NF, z.RH, "rhythm");
+        combine(E, prh.off, Q_ * NF, z.RH, z.RH, urh.off - prh.off, 2, rhythm);
+    } else {
+        named["bars"] = bars; named["rhythm"] = rhythm;
+    }
+
+    m = "style_encoder";
+    T se_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.SE_IL, ACT_LEAKY);
+    T se_ml = linear(E, RS1, {seg0(mode, false)}, m + ".mode_linear.weight", m + ".mode_linear.bias", z.SE_ML, ACT_LEAKY);
+    T se_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.SE_BL, ACT_LEAKY);
+    T sel = newT(R, z.SE_L);
+    lstm(E, rsR, {seg(bars, 1, 0, 0, 0)}, 1, R, z.SE_L, 0, m + ".bars_lstm", sel, 0);
+    T sel_last{sel.off + (int64_t)(R - 1) * z.SE_L, 1, z.SE_L, z.SE_L};
+    T se_lin = linear(E, rsC, {seg0(sel_last, true), seg(se_il, 1, 0, 0, 0), seg0(se_ml, true), seg0(se_bp, true)},
+                      m + ".linear.weight", m + ".linear.bias", z.STYLE, ACT_LEAKY);
+    T style = newT(1, z.STYLE, "style");
+    combine(E, se_lin.off, 1, z.STYLE, z.STYLE, z.STYLE, C, style);
+
+    m = "melody_encoder";
+    T me_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.ME_IL, ACT_LEAKY);
+    T me_bl = linear(E, rsP, {seg(pbeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.ME_BL, ACT_LEAKY);
+    T me_br = linear(E, rsR, {seg(pbars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.ME_BRL, ACT_LEAKY);
+    const int rsCRT[4] = {C, R, Tn, 1};
+    std::vector<SegIn> ysegs = {seg(me_bl, R * Tn, Tn, 1, 0), seg(me_br, 0, 1, 0, 0), seg(me_il, 1, 0, 0, 0)};
+    T me_oct = linear(E, rsCRT, ysegs, m + ".octave_linear.weight", m + ".octave_linear.bias", z.MEL * NOCT, ACT_LEAKY);
+    T me_deg = linear(E, rsCRT, ysegs, m + ".scale_degree_linear.weight", m + ".scale_degree_linear.bias", z.MEL * NDEG, ACT_LEAKY);
+    T mel_c = newT(P_ * NF * NPN, z.MEL);
+    {
+        NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
+        n.oct_off = me_oct.off; n.deg_off = me_deg.off; n.x_off = 0; n.x_space = SP_EXT0;
+        n.wc_off = pt.off(m + ".channels_linear.weight"); n.bc_off = pt.off(m + ".channels_linear.bias");
+        n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
+        n.out_off = mel_c.off; n.g_out_off = mel_c.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
+        const int nw = z.ME_CW * NPF + z.ME_CW + z.MEL * (z.MEL + z.ME_CW) + z.MEL;
+        n.nblk = P_ < 256 ? P_ : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        Op op; op.stage = E;
+        op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
+        notes.push_back(n); ops.push_back(op);
+        // channels_linear.{weight,bias}, linear.{weight,bias} are contiguous in the flat buffer
+        slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk});
+    }
+    T melody = newT(Q_ * NF * NPN, z.MEL, "melody");
+    combine(E, mel_c.off, Q_ * NF * NPN, z.MEL, z.MEL, (int64_t)Q_ * NF * NPN * z.MEL, C, melody);
+    stage_end[0] = act_top;
+
+    // ================================================================= stage 2: predict_song_info
+    stage_begin[1] = act_top;
+    m = "song_info_model";
+    T rhy_rows{rhythm.off, Q_, NF * z.RH, NF * z.RH};                    // squash_dims(rhythm, -2)
+    T sbl = newT(Q_, z.SIM_BL);
+    lstm(IN, rsQ, {seg(rhy_rows, 1, 0, 0, 0)}, R, Tn, z.SIM_BL, 0, m + ".beats_lstm.module", sbl, 0);
+    T slast{sbl.off + (int64_t)(Tn - 1) * z.SIM_BL, R, z.SIM_BL, Tn * z.SIM_BL};
+    T sbr = newT(R, z.NRF);
+    lstm(IN, rsR, {seg(slast, 1, 0, 0, 0)}, 1, R, z.NRF, 0, m + ".bars_lstm", sbr, 0);
+    T feats{sbr.off + (int64_t)(R - 1) * z.NRF, 1, z.NRF, z.NRF};
+    struct Head { const char* nm; int sw, rw, n, act; const char* out; };
+    const Head heads[3] = {{"instruments", z.SIM_SI, z.SIM_RI, z.NI, ACT_NONE, "instruments_pred"},
+                           {"mode", z.SIM_SM, z.SIM_RM, 2, ACT_NONE, "mode_pred"},
+                           {"bpm", z.SIM_SB, z.SIM_RB, 1, ACT_BPM, "bpm_pred"}};
+    for (const Head& h : heads) {
+        const std::string a = m + ".style_" + h.nm + "_linear", b2 = m + ".rhythm_" + h.nm + "_linear", c = m + "." + h.nm + "_linear";
+        T hs = linear(IN, RS1, {seg0(style, true)}, a + ".weight", a + ".bias", h.sw, ACT_LEAKY);
+        T hr = linear(IN, RS1, {seg0(feats, true)}, b2 + ".weight", b2 + ".bias", h.rw, ACT_LEAKY);
+        linear(IN, RS1, {seg0(hs, true), seg0(hr, true)}, c + ".weight", c + ".bias", h.n, h.act, nullptr, 0, 0, h.out);
+    }
+    stage_end[1] = act_top;
+
+    // ================================================================= stage 3: apply_style
+    stage_begin[2] = act_top;
+    m = "pitched_style_applier";
+    const int rsQF1[4] = {Q_ * NF, 1, 1, 1};
+    T psa_sl = linear(AP, RS1, {seg0(style, true)}, m + ".style_linear.weight", m + ".style_linear.bias", z.PSA_SL, ACT_LEAKY);
+    T psa_rl = linear(AP, rsQF1, {seg(rhythm, 1, 0, 0, 0)}, m + ".rhythm_linear.weight", m + ".rhythm_linear.bias", z.PSA_RL, ACT_LEAKY);
+    T psa_il = linear(AP, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PSA_IL, ACT_LEAKY);
+    const int rsCQF[4] = {C, Q_ * NF, 1, 1};
+    std::vector<SegIn> asegs = {seg0(psa_sl, true), seg(psa_rl, 0, 1, 0, 0), seg(psa_il, 1, 0, 0, 0)};
+    T lo = linear(AP, rsCQF, asegs, m + ".octave_linear.weight", m + ".octave_linear.bias", NPF * 6 * NOCT, ACT_LEAKY);
+    T ld_ = linear(AP, rsCQF, asegs, m + ".scale_degree_linear.weight", m + ".scale_degree_linear.bias", NPF * 6 * NDEG, ACT_LEAKY);
+    const int rsQFN[4] = {Q_ * NF * NPN, 1, 1, 1};
+    T ml = linear(AP, rsQFN, {seg(melody, 1, 0, 0, 0)}, m + ".melody_linear.weight", m + ".melody_linear.bias", z.PSA_ML, ACT_LEAKY);
+    T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
+    {
+        NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
+        n.oct_off = lo.off; n.deg_off = ld_.off; n.ml_off = ml.off;
+        n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
+        n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
+        const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
+        const int qf = Q_ * NF;
+        n.nblk = qf < 512 ? qf : 512; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        Op op; op.stage = AP;
+        op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
+        notes.push_back(n); ops.push_back(op);
+        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk});
+    }
+    if (U) {
+        m = "unpitched_style_applier";
+        T usa_sl = linear(AP, RS1, {seg0(style, true)}, m + ".style_linear.weight", m + ".style_linear.bias", NF * z.USA_SL, ACT_LEAKY);
+        T usa_rl = linear(AP, rsQF1, {seg(rhythm, 1, 0, 0, 0)}, m + ".rhythm_linear.weight", m + ".rhythm_linear.bias", z.USA_RL, ACT_LEAKY);
+        T sl_view{usa_sl.off, NF, z.USA_SL, z.USA_SL};                   // x.view(1, 1, 1, n_beat_fractions, -1)
+        const int rsQ_F[4] = {Q_, NF, 1, 1};
+        T v = linear(AP, rsQ_F, {seg(sl_view, 0, 1, 0, 0), seg(usa_rl, NF, 1, 0, 0)}, m + ".notes_linear.weight",
+                     m + ".notes_linear.bias", NUN * NUF * 4, ACT_LEAKY);
+        T v_rows{v.off, Q_ * NF * NUN, NUF * 4, NUF * 4};                  // x.view(..., n_unpitched_notes, -1)
+        const int rsQFU[4] = {Q_ * NF * NUN, 1, 1, 1};
+        linear(AP, rsQFU, {seg(v_rows, 1, 0, 0, 0)}, m + ".linear.weight", m + ".linear.bias", NUF, ACT_SIGOUT, nullptr, 0, 0,
+               "unpitched_pred");
+    }
+    stage_end[2] = act_top;
+    if (!notes_widths_supported(z.MEL, z.ME_CW, z.PSA_ML)) err = MST_ERR_UNSUPPORTED;
+    if (z.H > 256 || z.SE_L > 256 || z.HB > 256) err = MST_ERR_UNSUPPORTED;
+}
+
+template <class D>
+static int up(const std::vector<D>& v, D** dev) {
+    *dev = nullptr;
+    if (v.empty()) return 0;
+    if (hipMalloc((void**)dev, v.size() * sizeof(D)) != hipSuccess) return MST_ERR_ALLOC;
+    if (hipMemcpy(*dev, v.data(), v.size() * sizeof(D), hipMemcpyHostToDevice) != hipSuccess) return MST_ERR_ALLOC;
+    return 0;
+}
+
+int mst_plan::upload() {
+    int e = 0;
+    e |= up(gemms, &d_gemms); e |= up(segreds, &d_segreds); e |= up(lstms, &d_lstms);
+    e |= up(combines, &d_combines); e |= up(notes, &d_notes);
+    for (int s = 0; s < 3; ++s) {
+        e |= up(slabs[s], &d_slabs[s]);
+        for (auto& x : slabs[s]) if (x.count > slab_max[s]) slab_max[s] = x.count;
+    }
+    return e ? MST_ERR_ALLOC : MST_OK;
+}
+
+extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
+    int32_t dummy; if (!status) status = &dummy;
+    if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
+    mst_plan* p = new mst_plan();
+    p->d = *d; p->z = mst_sizes(*d);
+    build_params(*d, p->z, p->pt);
+    p->build();
+    if (p->err) { *status = p->err; delete p; return nullptr; }
+    int e = p->upload();
+    if (e) { *status = e; mst_plan_destroy(p); return nullptr; }
+    *status = MST_OK;
+    return p;
+}
+
+extern "C" void mst_plan_destroy(mst_plan* p) {
+    if (!p) return;
+    hipFree(p->d_gemms); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
+    for (int s = 0; s < 3; ++s) hipFree(p->d_slabs[s]);
+    delete p;
+}
+
+extern "C" int64_t mst_plan_workspace_floats(const mst_plan* p) { return p ? 2 * p->act_top + p->tmp_top : MST_ERR_ARG; }
+
+extern "C" int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t* off, int64_t* goff, int64_t* numel) {
+    if (!p || !name) return MST_ERR_ARG;
+    auto it = p->named.find(name);
+    if (it == p->named.end()) return MST_ERR_ARG;
+    if (off) *off = it->second.off;
+    if (goff) *goff = p->act_top + it->second.off;
+    if (numel) *numel = (int64_t)it->second.rows * it->second.cols;
+    return MST_OK;
+}
+
+extern "C" int32_t mst_plan_launch_count(const mst_plan* p, int32_t mask, int32_t backward) {
+    if (!p) return MST_ERR_ARG;
+    int n = 0;
+    for (auto& op : p->ops) {
+        if (!(op.stage & mask)) continue;
+        for (auto& s : (backward ? op.bwd : op.fwd)) n += (s.kind == K_COMB_F || s.kind == K_COMB_B) ? 2 : 1;
+    }
+    if (backward) for (int s = 0; s < 3; ++s) if ((mask >> s) & 1) n += 1;
+    return n;
+}
+
+static Bases make_bases(const mst_plan* p, const float* params, float* gparams, float* ws, const float* pitched,
+                        const float* unpitched) {
+    Bases b;
+    b.p[SP_WS] = ws; b.p[SP_PAR] = const_cast<float*>(params); b.p[SP_GPAR] = gparams;
+    b.p[SP_EXT0] = const_cast<float*>(pitched); b.p[SP_EXT1] = const_cast<float*>(unpitched);
+    b.p[SP_GRAD] = ws + p->act_top; b.p[SP_TMP] = ws + 2 * p->act_top;
+    return b;
+}
+
+static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
+    switch (s.kind) {
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, s.b, b, st);
+    case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, b, st);
+    case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
+    case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
+    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, p->combines[s.first], b, st);
+    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, p->combines[s.first], b, st);
+    case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
+    case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->notes[s.first], b, st);
+    case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
+    case K_PSA_B: return launch_psa_notes_bwd(p->d_notes + s.first, p->notes[s.first], b, st);
+    }
+    return MST_ERR_ARG;
+}
+
+extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* params, float* ws, const float* pitched,
+                               const float* unpitched, mst_stream stream) {
+    if (!p || !params || !ws) return MST_ERR_ARG;
+    if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
+    const Bases b = make_bases(p, params, nullptr, ws, pitched, unpitched);
+    for (auto& op : p->ops) {
+        if (!(op.stage & mask)) continue;
+        for (auto& s : op.fwd) {
+            int e = run_step(p, s, b, (hipStream_t)stream);
+            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
+        }
+    }
+    return MST_OK;
+}
+
+extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
+    if (!p || !ws) return MST_ERR_ARG;
+    for (int s = 0; s < 3; ++s) {
+        if (!((mask >> s) & 1)) continue;
+        const int64_t n = p->stage_end[s] - p->stage_begin[s];
+        if (n > 0 && hipMemsetAsync(ws + p->act_top + p->stage_begin[s], 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return MST_ERR_LAUNCH;
+    }
+    return MST_OK;
+}
+
+extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* params, float* gparams, float* ws,
+                                const float* pitched, const float* unpitched, mst_stream stream) {
+    if (!p || !params || !gparams || !ws) return MST_ERR_ARG;
+    if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
+    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    for (size_t i = p->ops.size(); i-- > 0;) {
+        const Op& op = p->ops[i];
+        if (!(op.stage & mask)) continue;
+        for (auto& s : op.bwd) {
+            int e = run_step(p, s, b, (hipStream_t)stream);
+            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
+        }
+    }
+    for (int s = 2; s >= 0; --s) {
+        if (!((mask >> s) & 1)) continue;
+        if (launch_slab_reduce(p->d_slabs[s], (int)p->slabs[s].size(), p->slab_max[s], b, (hipStream_t)stream))
+            return MST_ERR_LAUNCH;
+    }
+    return MST_OK;
+}
+
+__global__ void onehot_kernel(float* p, int n, int hot) {
+    const int i = threadIdx.x;
+    if (i < n) p[i] = i == hot ? 1.f : 0.f;
+}
+
+extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
+                                       const float* pitched, const float* unpitched, float* losses, mst_stream stream) {
+    if (!p || !params || !gparams || !ws || !pitched) return MST_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int e = mst_zero_grads(p, MST_STAGE_ALL, ws, stream);
+    if (e) return e;
+    e = mst_forward(p, MST_STAGE_ALL, params, ws, pitched, unpitched, stream);
+    if (e) return e;
+    const bool U = p->d.has_unpitched != 0;
+    float* g = ws + p->act_top;
+    auto at = [&](const char* n) { return p->named.at(n).off; };
+    const int64_t np = (int64_t)p->P() * NF * NPN, nu = U ? (int64_t)p->Q() * NF * NUN : 0;
+    float* lscratch = ws + 2 * p->act_top + p->loss_scratch;
+    e = mst_total_loss_fwd(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
+                           nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
+                           ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), 1, ws + p->t_losses.off,
+                           ws + p->t_saved.off, lscratch, stream);
+    if (e) return e;
+    hipLaunchKernelGGL(onehot_kernel, dim3(1), dim3(64), 0, st, ws + p->t_gl.off, (int)MST_N_LOSSES, (int)MST_L_TOTAL);
+    e = mst_total_loss_bwd(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
+                           nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
+                           ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off,
+                           ws + p->t_gl.off, g + at("pitched_pred"), U ? g + at("unpitched_pred") : nullptr,
+                           g + at("instruments_pred"), g + at("mode_pred"), g + at("bpm_pred"), stream);
+    if (e) return e;
+    e = mst_backward(p, MST_STAGE_ALL, params, gparams, ws, pitched, unpitched, stream);
+    if (e) return e;
+    if (losses && hipMemcpyAsync(losses, ws + p->t_losses.off, MST_N_LOSSES * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return MST_ERR_LAUNCH;
+    return MST_OK;
+}
+
+extern "C" const char* mst_version(void) { return "mst_amd 0.1 (gfx950)"; }

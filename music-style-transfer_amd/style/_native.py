@@ -1,0 +1,197 @@
+"""ctypes binding of libmst_amd.so (include/mst_amd.h) — plumbing only.
+
+The product always loads `music-style-transfer_amd/libmst_amd.so` (hipcc, gfx950) and raises
+if it is missing: there is no CPU fallback.  Tests may bind another build of the *same* C ABI
+(the hipsim interpreter build of the same .hip sources) by passing an explicit path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'libmst_amd.so')
+
+STAGE_EXTRACT, STAGE_INFO, STAGE_APPLY, STAGE_ALL = 1, 2, 4, 7
+LOSS_SAVED = 512
+LOSS_KEYS = [
+    'total', 'channels_loss_total', 'channels_loss_pitched_total', 'channels_loss_pitched_notes_loss',
+    'channels_loss_pitched_velocity_loss', 'channels_loss_pitched_duration_loss',
+    'channels_loss_pitched_accidentals_loss', 'channels_loss_unpitched_total',
+    'channels_loss_unpitched_notes_loss', 'channels_loss_unpitched_velocity_loss',
+    'channels_loss_unpitched_duration_loss', 'song_info_loss_total', 'song_info_loss_instruments_loss',
+    'song_info_loss_mode_loss', 'song_info_loss_bpm_loss',
+]
+N_LOSSES = len(LOSS_KEYS)
+
+
+class MstError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('C', 'R', 'T', 'beat', 'bar', 'nrf', 'style', 'melody', 'rhythm',
+                                         'instr', 'n_instruments', 'has_unpitched')]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_P = C.c_void_p
+_SIGS = {
+    'mst_param_count': (C.c_int32, [C.POINTER(Dims)]),
+    'mst_param_floats': (C.c_int64, [C.POINTER(Dims)]),
+    'mst_param_info': (C.c_int32, [C.POINTER(Dims), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32 * 3)]),
+    'mst_plan_create': (_P, [C.POINTER(Dims), C.POINTER(C.c_int32)]),
+    'mst_plan_destroy': (None, [_P]),
+    'mst_plan_workspace_floats': (C.c_int64, [_P]),
+    'mst_plan_tensor': (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'mst_plan_launch_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    'mst_forward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    'mst_backward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    'mst_zero_grads': (C.c_int32, [_P, C.c_int32, _P, _P]),
+    'mst_loss_scratch_floats': (C.c_int64, []),
+    'mst_total_loss_fwd': (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P,
+                                       C.c_int32, _P, _P, _P, _P]),
+    'mst_total_loss_bwd': (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _P, _P, _P, _P]),
+    'mst_train_iteration': (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    'mst_adam_step': (C.c_int32, [_P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_int32, C.c_double, C.c_int32, _P]),
+    'mst_hard_output': (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P]),
+    'mst_version': (C.c_char_p, []),
+}
+
+
+def ptr(t):
+    """Raw address of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MstError('mst_amd kernels take contiguous float32 tensors')
+    return t.data_ptr()
+
+
+def check(status, what):
+    if status != 0:
+        names = {-1: 'MST_ERR_ARG', -2: 'MST_ERR_UNSUPPORTED', -3: 'MST_ERR_LAUNCH', -4: 'MST_ERR_ALLOC'}
+        raise MstError(f'{what} failed: {names.get(status, status)}')
+
+
+class Native:
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise MstError(
+                f'{path} not found: the HIP library has not been built. Run `python -c "import __graft_entry__ as g; '
+                f'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.lib, name)      # raises AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        self._plans = {}
+
+    # ---- parameter layout
+    def param_table(self, dims):
+        n = self.lib.mst_param_count(C.byref(dims))
+        if n <= 0:
+            raise MstError('bad dims')
+        out = []
+        buf = C.create_string_buffer(256)
+        off, nd, shp = C.c_int64(), C.c_int32(), (C.c_int32 * 3)()
+        for i in range(n):
+            check(self.lib.mst_param_info(C.byref(dims), i, buf, 256, C.byref(off), C.byref(nd), C.byref(shp)), 'mst_param_info')
+            out.append((buf.value.decode(), off.value, tuple(shp[k] for k in range(nd.value))))
+        return out
+
+    def param_floats(self, dims):
+        return self.lib.mst_param_floats(C.byref(dims))
+
+    def plan(self, dims, device):
+        key = (dims.key(), str(device))
+        if key not in self._plans:
+            self._plans[key] = Plan(self, dims, device)
+        return self._plans[key]
+
+
+def current_stream(device):
+    if torch.device(device).type == 'cuda':
+        return torch.cuda.current_stream(device).cuda_stream
+    return None
+
+
+class Plan:
+    """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
+
+    def __init__(self, native, dims, device):
+        self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
+        st = C.c_int32()
+        self.handle = self.lib.mst_plan_create(C.byref(dims), C.byref(st))
+        if not self.handle:
+            check(st.value or -1, 'mst_plan_create')
+        n = self.lib.mst_plan_workspace_floats(self.handle)
+        self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._slots = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.mst_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def slot(self, name):
+        if name not in self._slots:
+            off, goff, numel = C.c_int64(), C.c_int64(), C.c_int64()
+            check(self.lib.mst_plan_tensor(self.handle, name.encode(), C.byref(off), C.byref(goff), C.byref(numel)),
+                  f'mst_plan_tensor({name})')
+            self._slots[name] = (off.value, goff.value, numel.value)
+        return self._slots[name]
+
+    def view(self, name, shape=None):
+        off, _, n = self.slot(name)
+        t = self.ws[off:off + n]
+        return t.view(*shape) if shape is not None else t
+
+    def grad(self, name, shape=None):
+        _, goff, n = self.slot(name)
+        t = self.ws[goff:goff + n]
+        return t.view(*shape) if shape is not None else t
+
+    def set_inputs(self, mode=None, bpm=None, instr=None, used=None, bpm_target=None):
+        for name, t in (('mode', mode), ('bpm', bpm), ('instr', instr), ('used_instruments', used), ('bpm_target', bpm_target)):
+            if t is not None:
+                self.view(name).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
+
+    def launch_count(self, mask=STAGE_ALL, backward=False):
+        return self.lib.mst_plan_launch_count(self.handle, mask, int(backward))
+
+    def forward(self, mask, params, pitched, unpitched):
+        check(self.lib.mst_forward(self.handle, mask, ptr(params), ptr(self.ws), ptr(pitched), ptr(unpitched),
+                                   current_stream(self.device)), 'mst_forward')
+
+    def backward(self, mask, params, gparams, pitched, unpitched):
+        check(self.lib.mst_backward(self.handle, mask, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched),
+                                    ptr(unpitched), current_stream(self.device)), 'mst_backward')
+
+    def zero_grads(self, mask):
+        check(self.lib.mst_zero_grads(self.handle, mask, ptr(self.ws), current_stream(self.device)), 'mst_zero_grads')
+
+    def train_iteration(self, params, gparams, pitched, unpitched, losses=None):
+        check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched),
+                                           ptr(unpitched), ptr(losses), current_stream(self.device)),
+              'mst_train_iteration')
+
+
+_native = None
+
+
+def get():
+    """The product library (raises MstError when it has not been built)."""
+    global _native
+    if _native is None:
+        _native = Native()
+    return _native
