@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — style-transfer optimisation iterations/sec (BASELINE.json metric).
+
+A "step" is one body of the reference's training loop (train-model.py:97-154): forward ->
+get_total_loss -> backward (gradients accumulate), with the Adam + StepLR step every
+iter_size = 2 iterations, on one synthetic "30 s" clip (C=4 pitched channels, R=16 bars, T=4
+beats, percussion channel present; BASELINE.json configs[1]).  Clips and
+parameters are resident in HBM before the timed region.  With N > 1 GPUs every rank owns its
+own clip (weak scaling) and the flat fp32 gradient buffer is all-reduced (SUM, RCCL over xGMI)
+before every optimizer step — the data-parallel form of the reference's gradient accumulation.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'music-style-transfer_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+WIDTHS = dict(beat=64, bar=128, nrf=8, style=256, melody=8, rhythm=32)
+CLIP = dict(C=4, R=16, T=4)
+ITER_SIZE = 2
+PEAK_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBS = 8000.0
+KIND_NAMES = {0: 'gemm_kernel', 1: 'segred_kernel', 2: 'lstm_fwd_kernel', 3: 'lstm_bwd_kernel', 4: 'combine_fwd',
+              5: 'combine_bwd', 6: 'me_notes_fwd_kernel', 7: 'me_notes_bwd_kernel', 8: 'psa_notes_fwd_kernel',
+              9: 'psa_notes_bwd_kernel'}
+
+
+def algorithmic_flops_per_iter(C, R, T, U=1):
+    """FLOP_fwd over the reference's (unfused) layer shapes; fwd+bwd = 3x."""
+    P, Q = C * R * T, R * T
+    fwd = 2470880 * P + 209288 * Q + 651328 * R + U * (934400 * Q + 141312 * R)
+    return 3 * fwd
+
+
+def init_params(native, dims, seed=108):
+    """Random-init weights of the reference architecture (uniform +-1/sqrt(fan_in), like nn.Linear)."""
+    table = native.param_table(dims)
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(native.param_floats(dims))
+    for name, off, shape in table:
+        n = int(np.prod(shape))
+        fan = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+        flat[off:off + n] = (torch.rand(n, generator=g) * 2 - 1) / fan ** 0.5
+    return flat, table
+
+
+def cpu_baseline(flat, table, clip, seconds):
+    """The oracle (torch-CPU port of the reference's path, pinned to its fixtures) on this host."""
+    from oracle import style_oracle as so
+    named = {n: flat[o:o + int(np.prod(s))].view(*s).clone().requires_grad_(True) for n, o, s in table}
+    opt = so.Adam(named.values())
+    so.iteration(named, clip, fast=True)          # warm
+    opt.step()
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        so.iteration(named, clip, fast=True)
+        it += 1
+        if it % ITER_SIZE == 0:
+            opt.step()
+        if time.perf_counter() - t0 >= seconds and it % ITER_SIZE == 0:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=it / dt, unit='iters/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{it} iterations of the same clip/config through oracle/style_oracle.py (torch CPU fp32, '
+                       f'mkldnn LSTM), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-kernel time table to stderr')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from oracle.synth import synth_clip
+    from style import _native as nat
+    native = nat.get()                     # raises if libmst_amd.so is missing: no fallback
+    dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+    flat, table = init_params(native, dims)
+    clip = synth_clip(rank, CLIP['C'], CLIP['R'], CLIP['T'], True)      # one clip per GPU
+    plan = native.plan(dims, dev)
+    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
+                    used=clip['used_instruments'], bpm_target=float(clip['bpm_int']))
+    params = flat.to(dev)
+    gparams = torch.zeros_like(params)
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    state = torch.zeros(4, device=dev)
+    xp, xu = clip['pitched'].contiguous().to(dev), clip['unpitched'].contiguous().to(dev)
+    losses = torch.zeros(nat.N_LOSSES, device=dev)
+    n = params.numel()
+    stream = torch.cuda.Stream(dev)
+
+    def iteration():
+        plan.train_iteration(params, gparams, xp, xu, losses)
+
+    def optimizer_step():
+        if dist is not None:
+            dist.all_reduce(gparams, op=dist.ReduceOp.SUM)          # sum, not mean: train-model.py:126,151-153
+        nat.check(native.lib.mst_adam_step(nat.ptr(params), nat.ptr(gparams), nat.ptr(m), nat.ptr(v), n, nat.ptr(state),
+                                           .01, .9, .999, 1e-8, 200, .9, 1, nat.current_stream(dev)), 'mst_adam_step')
+
+    graph_it = None
+    with torch.cuda.stream(stream):
+        iteration(); iteration(); optimizer_step()                    # load code objects, size RCCL buffers
+        stream.synchronize()
+        if not args.no_graph:
+            graph_it = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_it, stream=stream):
+                iteration()
+        run_it = graph_it.replay if graph_it is not None else iteration
+
+        def step(i):
+            run_it()
+            if (i + 1) % ITER_SIZE == 0:
+                optimizer_step()
+
+        for i in range(args.warmup):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(args.steps):
+            step(i)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        final_loss = float(losses.cpu()[0])
+        if dist is not None:
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.cpu()[0])
+
+        # ---- roofline leg: every launch step timed with HIP events on this stream (same workload)
+        roof, table_rows = None, []
+        if rank == 0:
+            steps = plan.time_steps(nat.STAGE_ALL, False, params, gparams, xp, xu, reps=20) + \
+                plan.time_steps(nat.STAGE_ALL, True, params, gparams, xp, xu, reps=20)
+            agg = {}
+            for kind, ms, fl, by in steps:
+                a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+                a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+            total_ms = sum(a[1] for a in agg.values())
+            for kind, (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                table_rows.append(dict(kernel=KIND_NAMES[kind], launches=cnt, total_us=round(ms * 1e3, 1),
+                                       avg_us=round(ms * 1e3 / cnt, 2), share=round(ms / total_ms, 3),
+                                       gflop=round(fl / 1e9, 4), mbytes=round(by / 1e6, 2)))
+            kind, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+            achieved = fl / (ms * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel=KIND_NAMES[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+                        flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
+                        frac=achieved / PEAK_F32_TFLOPS, traffic=None,
+                        whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
+                                             achieved_tflops=algorithmic_flops_per_iter(**CLIP) / (dt / args.steps) / 1e12))
+            if args.breakdown:
+                for r in table_rows:
+                    print(json.dumps(r), file=sys.stderr)
+
+    ips = world * args.steps / dt
+    out = dict(metric='style-transfer opt iters/sec', value=ips, unit='iters/s', n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload='one 30 s clip per GPU as piano-roll C=4,R=16,T=4 (+percussion), full widths '
+                                    '(980325 params), fwd+loss+bwd every step, Adam+StepLR every 2nd step '
+                                    '(BASELINE.json configs[1])',
+                           clips_per_gpu=1, iter_size=ITER_SIZE, hip_graph=graph_it is not None,
+                           launches_per_iteration=plan.launch_count(7, False) + plan.launch_count(7, True) + 5,
+                           parallelism=f'dp{world} (RCCL all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
+                           device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))
+    if rank == 0:
+        out['roofline'] = roof
+        out['kernel_breakdown'] = table_rows
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(flat, table, clip, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -127,6 +127,14 @@ int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_av
  * Like the reference it also zeroes sub-threshold velocities of `x` in place. */
 int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_stream stream);
 
+/* ---- instrumentation (bench.py only; synchronises on HIP events, never used for training):
+ * average duration of every launch step of a pass, with its algorithmic FLOPs and bytes.
+ * kind: 0 gemm, 1 segment-reduce, 2/3 lstm fwd/bwd, 4/5 combine fwd/bwd, 6/7 melody notes, 8/9 applier notes. */
+int32_t mst_plan_step_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
+int32_t mst_plan_time_steps(const mst_plan* p, int32_t stage_mask, int32_t backward, const float* params,
+                            float* gparams, float* ws, const float* pitched, const float* unpitched,
+                            mst_stream stream, int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes);
+
 const char* mst_version(void);
 
 #ifdef __cplusplus

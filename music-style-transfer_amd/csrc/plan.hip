@@ -770,4 +770,95 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     return MST_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ instrumentation
+// Per-launch-step timing with HIP events recorded on the caller's stream (bench.py's roofline leg).
+// Not graph-capturable (it synchronises on events) and never called from the training path.
+static void step_cost(const mst_plan* p, const Step& s, double* flops, double* bytes) {
+    double f = 0, b = 0;
+    switch (s.kind) {
+    case K_GEMM:
+        for (int i = 0; i < s.count; ++i) {
+            const GemmDesc& g = p->gemms[s.first + i];
+            f += 2.0 * g.M * g.N * g.K;
+            b += 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N);
+        }
+        break;
+    case K_SEGRED:
+        for (int i = 0; i < s.count; ++i) {
+            const SegRedDesc& r = p->segreds[s.first + i];
+            const double rows = (double)r.d[0] * r.d[1] * r.d[2] * r.d[3];
+            f += rows * r.width; b += 4.0 * (rows * r.width + 2.0 * r.nidx * r.width);
+        }
+        break;
+    case K_LSTM_F: case K_LSTM_B:
+        for (int i = 0; i < s.count; ++i) {
+            const LstmDesc& l = p->lstms[s.first + i];
+            f += (double)l.B * l.S * (8.0 * l.H * l.H + 30.0 * l.H);
+            b += 4.0 * ((double)l.B * l.S * 11.0 * l.H + 4.0 * l.H * l.H);
+        }
+        break;
+    case K_COMB_F: case K_COMB_B: {
+        const CombineDesc& c = p->combines[s.first];
+        const double n = (double)c.rows * c.cols;
+        f = n * c.Cn * (s.kind == K_COMB_F ? 4.0 : 8.0);
+        b = 4.0 * n * (s.kind == K_COMB_F ? 2.0 * c.Cn + 1 : 4.0 * c.Cn + 2);
+        break;
+    }
+    case K_ME_F: case K_ME_B: {
+        const NotesDesc& n = p->notes[s.first];
+        const double pos = (double)n.C * n.Q * NF * NPN;
+        const double per = 2.0 * n.W + 2.0 * n.CW * NPF + 2.0 * n.W * (n.W + n.CW);
+        f = pos * per * (s.kind == K_ME_F ? 1.0 : 3.0);
+        b = 4.0 * pos * (NPF + n.W * (s.kind == K_ME_F ? 1.0 : 2.0));
+        break;
+    }
+    case K_PSA_F: case K_PSA_B: {
+        const NotesDesc& n = p->notes[s.first];
+        const double pos = (double)n.C * n.Q * NF * NPN;
+        const double per = 2.0 * 30 + 2.0 * NPF * (30 + n.ML);
+        f = pos * per * (s.kind == K_PSA_F ? 1.0 : 3.0);
+        b = 4.0 * (pos * NPF * (s.kind == K_PSA_F ? 1.0 : 2.0) + (double)n.C * n.Q * NF * 450 * (s.kind == K_PSA_F ? 1.0 : 2.0) +
+                   (double)n.Q * NF * NPN * n.ML * (s.kind == K_PSA_F ? 1.0 : 2.0));
+        break;
+    }
+    }
+    *flops = f; *bytes = b;
+}
+
+extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t backward) {
+    if (!p) return MST_ERR_ARG;
+    int n = 0;
+    for (auto& op : p->ops) if (op.stage & mask) n += (int)(backward ? op.bwd.size() : op.fwd.size());
+    return n;
+}
+
+extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t backward, const float* params, float* gparams,
+                                       float* ws, const float* pitched, const float* unpitched, mst_stream stream,
+                                       int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes) {
+    if (!p || !params || !ws || !ms || !kind || !flops || !bytes || reps < 1) return MST_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MST_ERR_ALLOC;
+    std::vector<const Step*> steps;
+    if (!backward) { for (auto& op : p->ops) if (op.stage & mask) for (auto& s : op.fwd) steps.push_back(&s); }
+    else { for (size_t i = p->ops.size(); i-- > 0;) if (p->ops[i].stage & mask) for (auto& s : p->ops[i].bwd) steps.push_back(&s); }
+    int idx = 0;
+    for (const Step* s : steps) {
+        run_step(p, *s, b, st);                       // warm
+        hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r) run_step(p, *s, b, st);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float t = 0.f;
+        hipEventElapsedTime(&t, e0, e1);
+        ms[idx] = t / reps; kind[idx] = s->kind;
+        step_cost(p, *s, &flops[idx], &bytes[idx]);
+        ++idx;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return idx;
+}
+
 extern "C" const char* mst_version(void) { return "mst_amd 0.1 (gfx950)"; }

@@ -60,6 +60,8 @@ _SIGS = {
     'mst_adam_step': (C.c_int32, [_P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_int32, C.c_double, C.c_int32, _P]),
     'mst_hard_output': (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P]),
+    'mst_plan_step_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    'mst_plan_time_steps': (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     'mst_version': (C.c_char_p, []),
 }
 
@@ -179,6 +181,19 @@ class Plan:
 
     def zero_grads(self, mask):
         check(self.lib.mst_zero_grads(self.handle, mask, ptr(self.ws), current_stream(self.device)), 'mst_zero_grads')
+
+    def time_steps(self, mask, backward, params, gparams, pitched, unpitched, reps=20):
+        """[(kind, avg_ms, flops, bytes)] per launch step (HIP events on the current stream)."""
+        import numpy as np
+        n = self.lib.mst_plan_step_count(self.handle, mask, int(backward))
+        ms, kind = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        fl, by = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        got = self.lib.mst_plan_time_steps(self.handle, mask, int(backward), ptr(params), ptr(gparams), ptr(self.ws),
+                                           ptr(pitched), ptr(unpitched), current_stream(self.device), reps,
+                                           ms.ctypes.data, kind.ctypes.data, fl.ctypes.data, by.ctypes.data)
+        if got != n:
+            check(got if got < 0 else -1, 'mst_plan_time_steps')
+        return list(zip(kind.tolist(), ms.tolist(), fl.tolist(), by.tolist()))
 
     def train_iteration(self, params, gparams, pitched, unpitched, losses=None):
         check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched),

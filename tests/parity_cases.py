@@ -1,0 +1,139 @@
+"""Parity cases shared by the CPU-interpreter tests and the -m gpu tests: both drive the SAME
+C ABI (include/mst_amd.h); only the library build (hipsim vs hipcc/gfx950) and the device differ."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import style_oracle as so
+from oracle.synth import synth_clip
+from simutil import GOLDEN, flat_from_named, make_dims, rel
+from style import _native as nat
+
+SMALL = dict(beat=8, bar=6, nrf=3, style=12, melody=4, rhythm=6)
+FULL = dict(beat=64, bar=128, nrf=8, style=256, melody=8, rhythm=32)
+TOL = 1e-4          # rel-L2 tolerance of north_star ("within 1e-4 rel-L2 of the CPU reference")
+
+
+def set_clip(plan, clip):
+    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
+                    used=clip['used_instruments'], bpm_target=float(clip['bpm_int']))
+
+
+def dev_clip(clip, device):
+    return clip['pitched'].contiguous().to(device), (None if clip['unpitched'] is None else clip['unpitched'].contiguous().to(device))
+
+
+def golden_small(native, device, name):
+    """Fixture produced by the reference: forward mids, 15 loss leaves, every gradient, 2-clip Adam step."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    unp = bool(z['unpitched'])
+    dims = make_dims(SMALL, C, R, T, unp)
+    params, table = flat_from_named(native, dims, {k[3:]: z[k] for k in z.files if k.startswith('p0/')})
+    params = params.to(device)
+    plan = nat.Plan(native, dims, device)
+    clip = synth_clip(0, C, R, T, unp, density=float(z['density']))
+    set_clip(plan, clip)
+    gparams = torch.zeros_like(params)
+    losses = torch.zeros(nat.N_LOSSES, device=device)
+    xp, xu = dev_clip(clip, device)
+    plan.train_iteration(params, gparams, xp, xu, losses)
+    checks = [('pitched_beats', 'mid/pitched_channels_encoder/0'), ('pitched_bars', 'mid/pitched_channels_encoder/1'),
+              ('pitched_rhythm', 'mid/pitched_rhythm_encoder/0'), ('style', 'mid/style_encoder/0'),
+              ('melody', 'mid/melody_encoder/0'), ('instruments_pred', 'out/instruments'), ('mode_pred', 'out/mode'),
+              ('bpm_pred', 'out/bpm'), ('pitched_pred', 'out/pitched')]
+    if unp:
+        checks += [('unpitched_beats', 'mid/unpitched_channels_encoder/0'), ('unpitched_bars', 'mid/unpitched_channels_encoder/1'),
+                   ('unpitched_rhythm', 'mid/unpitched_rhythm_encoder/0'), ('unpitched_pred', 'out/unpitched')]
+    for slot, key in checks:
+        e = rel(plan.view(slot).cpu().numpy(), z[key])
+        assert e < TOL, (slot, e)
+    lc = losses.cpu()
+    for i, k in enumerate(nat.LOSS_KEYS):
+        if 'loss0/' + k in z.files:
+            assert abs(float(lc[i]) - float(z['loss0/' + k])) < 2e-5, (k, float(lc[i]), float(z['loss0/' + k]))
+        else:
+            assert np.isnan(float(lc[i])), k
+    gc = gparams.cpu()
+    bad = []
+    for pname, off, shape in table:
+        ref = z['g0/' + pname].reshape(-1)
+        got = gc[off:off + ref.size].numpy()
+        if np.linalg.norm(ref) < 1e-12:
+            if np.abs(got).max() > 1e-6:
+                bad.append((pname, 'nonzero', float(np.abs(got).max())))
+        elif rel(got, ref) > 5e-4:
+            bad.append((pname, rel(got, ref)))
+    assert not bad, bad
+    # second clip accumulates (sum), then Adam + StepLR + zero_grad (train-model.py:151-154)
+    clip1 = synth_clip(1, C, R, T, unp, density=float(z['density']))
+    set_clip(plan, clip1)
+    xp, xu = dev_clip(clip1, device)
+    plan.train_iteration(params, gparams, xp, xu, losses)
+    assert abs(float(losses.cpu()[0]) - float(z['loss1/total'])) < 2e-5
+    m, v, state = torch.zeros_like(params), torch.zeros_like(params), torch.zeros(4, device=device)
+    nat.check(native.lib.mst_adam_step(nat.ptr(params), nat.ptr(gparams), nat.ptr(m), nat.ptr(v), params.numel(),
+                                       nat.ptr(state), .01, .9, .999, 1e-8, 200, .9, 1, nat.current_stream(device)), 'adam')
+    assert float(state.cpu()[0]) == 1.0 and float(gparams.abs().max()) == 0.0
+    pc = params.cpu()
+    for pname, off, shape in table:
+        ref = z['p1/' + pname].reshape(-1)
+        assert np.abs(pc[off:off + ref.size].numpy() - ref).max() < 3e-4, pname
+
+
+def random_params(native, dims, seed=0):
+    table = native.param_table(dims)
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(native.param_floats(dims))
+    named = {}
+    for name, off, shape in table:
+        n = int(np.prod(shape))
+        fan = shape[1] * (shape[2] if len(shape) > 2 else 1) if len(shape) > 1 else shape[0]
+        flat[off:off + n] = (torch.rand(n, generator=g) * 2 - 1) / fan ** 0.5
+        named[name] = flat[off:off + n].view(*shape).clone().requires_grad_(True)
+    return flat, named, table
+
+
+def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density=0.02, check_bitwise=False):
+    """Same seeded inputs through the oracle (torch CPU autograd) and through the C ABI."""
+    dims = make_dims(widths, C, R, T, unp)
+    flat, named, table = random_params(native, dims, seed)
+    clip = synth_clip(clip_id, C, R, T, unp, density=density)
+    mids = {}
+    (info, xp_ref, xu_ref), ref_losses = so.iteration(named, clip, mids=mids)
+    plan = nat.Plan(native, dims, device)
+    set_clip(plan, clip)
+    params = flat.to(device)
+    gparams = torch.zeros_like(params)
+    losses = torch.zeros(nat.N_LOSSES, device=device)
+    xp, xu = dev_clip(clip, device)
+    plan.train_iteration(params, gparams, xp, xu, losses)
+    out = dict(style=mids['style'], melody=mids['melody'], rhythm=mids['rhythm'], pitched_pred=xp_ref,
+               instruments_pred=info[0], mode_pred=info[1], bpm_pred=info[2])
+    if unp:
+        out['unpitched_pred'] = xu_ref
+    for k, v in out.items():
+        e = rel(plan.view(k).cpu().numpy(), v.detach().numpy())
+        assert e < TOL, (k, e)
+    lc = losses.cpu()
+    for i, k in enumerate(nat.LOSS_KEYS):
+        if k in ref_losses:
+            assert abs(float(lc[i]) - ref_losses[k]) < 5e-5, (k, float(lc[i]), ref_losses[k])
+    gref = torch.cat([(named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])).reshape(-1)
+                      for n, _, _ in table])
+    gc = gparams.cpu()
+    e = rel(gc.numpy(), gref.numpy())
+    assert e < TOL, ('all gradients', e)
+    worst = 0.0
+    for pname, off, shape in table:
+        n = int(np.prod(shape))
+        r = gref[off:off + n]
+        if float(r.norm()) > 1e-7 * float(gref.norm()):
+            worst = max(worst, rel(gc[off:off + n].numpy(), r.numpy()))
+    assert worst < 2e-3, ('worst per-tensor gradient', worst)
+    if check_bitwise:   # fixed summation order everywhere: a second run must be bit-identical
+        g2 = torch.zeros_like(params)
+        plan.train_iteration(params, g2, xp, xu, losses)
+        assert torch.equal(g2, gparams)
+    return e, worst

@@ -1,0 +1,39 @@
+"""-m gpu: the hipcc/gfx950 build of the hot path on a real MI355X, through the C ABI, against
+the reference-generated fixtures and the oracle on the same seeded inputs."""
+import pytest
+import torch
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def native():
+    from style import _native as nat
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return nat.get()       # raises if libmst_amd.so is missing: no fallback
+
+
+@pytest.mark.parametrize('name', ['small_unpitched', 'small_pitched_only'])
+def test_golden_small(native, name):
+    pc.golden_small(native, torch.device('cuda:0'), name)
+
+
+@pytest.mark.parametrize('C,R,T,unp', [(1, 1, 1, True), (3, 2, 3, False), (2, 5, 1, True)])
+def test_oracle_small_widths_ragged_shapes(native, C, R, T, unp):
+    pc.oracle_case(native, torch.device('cuda:0'), pc.SMALL, C, R, T, unp, density=0.05, check_bitwise=True)
+
+
+def test_oracle_full_widths_small_clip(native):
+    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 2, 2, 4, True, check_bitwise=True)
+
+
+def test_oracle_bench_clip(native):
+    # BASELINE.json configs[1]: one "30 s" clip = (C=4, R=16, T=4), full widths
+    e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, check_bitwise=True)
+    print('bench clip: all-gradient rel-L2', e, 'worst tensor', worst)
+
+
+def test_oracle_pitched_only_many_channels(native):
+    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 8, 3, 3, False)
