@@ -32,9 +32,9 @@ CLIP = dict(C=4, R=16, T=4)
 ITER_SIZE = 2
 PEAK_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
-KIND_NAMES = {0: 'gemm_kernel', 1: 'segred_kernel', 2: 'lstm_fwd_kernel', 3: 'lstm_bwd_kernel', 4: 'combine_fwd',
-              5: 'combine_bwd', 6: 'me_notes_fwd_kernel', 7: 'me_notes_bwd_kernel', 8: 'psa_notes_fwd_kernel',
-              9: 'psa_notes_bwd_kernel'}
+KIND_NAMES = {0: 'gemm_kernel', 1: 'gather_kernel', 2: 'segred_kernel', 3: 'lstm_fwd_kernel', 4: 'lstm_bwd_kernel',
+              5: 'combine_fwd', 6: 'combine_bwd', 7: 'me_notes_fwd_kernel', 8: 'me_notes_bwd_kernel',
+              9: 'psa_notes_fwd_kernel', 10: 'psa_notes_bwd_kernel', 11: 'lstm_transpose_kernel'}
 
 
 def algorithmic_flops_per_iter(C, R, T, U=1):

@@ -8,7 +8,7 @@
 // the source tensors — and bias/activation (or the activation derivative on the backward
 // side) are fused into the tile load / epilogue.
 //
-// Tiling: 64x64x16 per 256-thread workgroup (4 waves of 64), 4x4 register micro-tile per
+// Tiling: 64x64x32 per 256-thread workgroup (4 waves of 64), 4x4 register micro-tile per
 // lane, LDS tiles stored k-major with a +4 pad so both the float4 fragment reads and the
 // transposed tile writes are (at worst 2-way) bank-conflict free.  blockIdx.y selects the
 // descriptor, so independent small GEMMs share one launch; blockIdx.z is the split of the
@@ -30,111 +30,106 @@ __device__ __forceinline__ float act_bwd(int act, float y, int col) {
     return 1.f;
 }
 
-__device__ __forceinline__ float fetch(const Operand& o, const Bases& b, int i, int j) {
-    switch (o.kind) {
-    case OPK_DENSE:
-        if (j == o.ones_at) return 1.f;
-        return b.p[o.space][o.off + (int64_t)i * o.si + (int64_t)j * o.sj];
-    case OPK_CAT: {
-        if (j == o.ones_at) return 1.f;
-        int r3 = i % o.d3; int t = i / o.d3;
-        int r2 = t % o.d2; t /= o.d2;
-        int r1 = t % o.d1; int r0 = t / o.d1;
-        int sidx = 0;
-#pragma unroll
-        for (int q = 1; q < MAX_SEG; ++q)
-            if (q < o.nseg && j >= o.seg[q].start) sidx = q;
-        const Seg& sg = o.seg[sidx];
-        int64_t row = (int64_t)r0 * sg.s[0] + (int64_t)r1 * sg.s[1] + (int64_t)r2 * sg.s[2] + (int64_t)r3 * sg.s[3];
-        return b.p[sg.space][sg.off + row * sg.ld + (j - sg.start)];
-    }
-    case OPK_ACTGRAD: {
-        int row = o.transposed ? j : i;
-        int col = o.transposed ? i : j;
-        int64_t idx = (int64_t)row * o.ld + col;
-        return b.p[o.space][o.off + idx] * act_bwd(o.act, b.p[o.space2][o.off2 + idx], col);
-    }
-    case OPK_IM2COL: {   // i = (p, octave), j = (fraction, tap, feature)
-        if (j == o.ones_at) return 1.f;
-        int p = i >> 3, oc = i & 7;
-        int f = j / (CONV_K * NPF), rem = j - f * (CONV_K * NPF);
-        int e = (NDEG * oc - CONV_PAD) * NPF + rem;
-        if (e < 0 || e >= NPN * NPF) return 0.f;
-        return b.p[o.space][o.off + (int64_t)p * (NF * NPN * NPF) + f * (NPN * NPF) + e];
-    }
-    case OPK_PERMW: {    // i = (a, b, c) in memory order of the activations, j = out feature.
+// ---- operand access ------------------------------------------------------------------------
+// Operand and epilogue kinds are template parameters, every operand is an affine function of its
+// two indices, element offsets are 32-bit, and all loads go through explicit global-address-space
+// pointers (a generic pointer would become flat_load, which also counts on lgkmcnt and so stalls
+// every LDS read of the FMA loop).  Loading is two-phase: compute every address of the next
+// k-tile, issue all loads unconditionally (padding / bias-ones columns read a constant from
+// memory instead of branching) so they fly under the current tile's FMAs, consume one tile later.
+__device__ const float k_const[2] = {0.f, 1.f};
+typedef const MST_GLOBAL_AS float* gcptr;
+
+struct Ld { gcptr p; gcptr p2; int col; };
+
+template <int KIND>
+__device__ __forceinline__ Ld addr_of(const Operand& o, gcptr base, gcptr base2, int i, int j, bool valid) {
+    Ld r; r.p = (gcptr)&k_const[0]; r.p2 = (gcptr)&k_const[1]; r.col = 0;
+    if (!valid) return r;
+    if constexpr (KIND == OPK_DENSE) {
+        r.p = (j == o.ones_at) ? (gcptr)&k_const[1] : base + (unsigned)(i * (int)o.si + j * (int)o.sj);
+    } else if constexpr (KIND == OPK_ACTGRAD) {
+        const int row = o.transposed ? j : i;
+        r.col = o.transposed ? i : j;
+        const unsigned idx = (unsigned)(row * o.ld + r.col);
+        r.p = base + idx;
+        r.p2 = base2 + idx;
+    } else if constexpr (KIND == OPK_IM2COL) {      // i = (p, octave), j = (fraction, tap, feature)
+        if (j == o.ones_at) { r.p = (gcptr)&k_const[1]; return r; }
+        const int p = i >> 3, oc = i & 7;
+        const int f = j / (CONV_K * NPF), rem = j - f * (CONV_K * NPF);
+        const int e = (NDEG * oc - CONV_PAD) * NPF + rem;
+        if (e >= 0 && e < NPN * NPF) r.p = base + (unsigned)(p * (NF * NPN * NPF) + f * (NPN * NPF) + e);
+    } else if constexpr (KIND == OPK_PERMW) {       // i = (a, b, c) in activation memory order, j = out feature
         // conv: (fraction, tap, feature) reads W[oc, fraction*5+feature, tap]  (pb=14, pc=5)
         // unpitched linear: (fraction, note, feature) reads W[j, fraction*94 + feature*47 + note]
         const int bc = o.pb * o.pc;
-        int a = i / bc, rem = i - a * bc;
-        int bb = rem / o.pc, c = rem - bb * o.pc;
-        return b.p[o.space][o.off + (int64_t)j * o.ld + a * bc + c * o.pb + bb];
+        const int a = i / bc, rem = i - a * bc;
+        const int bb = rem / o.pc, c = rem - bb * o.pc;
+        r.p = base + (unsigned)(j * o.ld + a * bc + c * o.pb + bb);
+    } else if constexpr (KIND == OPK_CONVGRAD) {    // i = out channel, j = (p, octave)
+        const int p = j >> 3, oc = j & 7;
+        const unsigned idx = (unsigned)(p * (o.oc * NOCT) + i * NOCT + oc);
+        r.p = base + idx;
+        r.p2 = base2 + idx;
     }
-    case OPK_CONVGRAD: { // i = out channel, j = (p, octave)
-        int p = j >> 3, oc = j & 7;
-        int64_t idx = (int64_t)p * (o.oc * NOCT) + i * NOCT + oc;
-        return b.p[o.space][o.off + idx] * act_bwd(ACT_LEAKY, b.p[o.space2][o.off2 + idx], 0);
-    }
-    }
-    return 0.f;
+    return r;
 }
 
-__device__ __forceinline__ void store_out(const GemmDesc& d, const Bases& b, int m, int n, int split, float acc) {
+template <int KIND>
+__device__ __forceinline__ float finish(const Operand& o, float v, float y, int col) {
+    if constexpr (KIND == OPK_ACTGRAD) return o.act == ACT_NONE ? v : v * act_bwd(o.act, y, col);
+    else if constexpr (KIND == OPK_CONVGRAD) return v * act_bwd(ACT_LEAKY, y, 0);
+    else return v;
+}
+
+template <int OK>
+__device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const float* bias, int m, int n, int split, float acc) {
     const OutSpec& o = d.out;
-    switch (o.kind) {
-    case OUT_STORE: {
+    if constexpr (OK == OUT_STORE) {
         float v = acc;
-        if (o.bias_space >= 0) v += b.p[o.bias_space][o.bias_off + n];
-        b.p[o.space][o.off + (int64_t)m * o.ldc + n] = act_fwd(o.act, v, n);
-        break;
-    }
-    case OUT_ACCUM:
-        b.p[o.space][o.off + (int64_t)m * o.ldc + n] += acc;
-        break;
-    case OUT_CONV: {     // m = (p, octave), n = out channel -> x1[p, n*8 + octave]
-        float v = acc + b.p[o.bias_space][o.bias_off + n];
-        b.p[o.space][o.off + (int64_t)(m >> 3) * o.ldc + n * NOCT + (m & 7)] = act_fwd(ACT_LEAKY, v, 0);
-        break;
-    }
-    case OUT_SLAB: {
-        int64_t base = o.off + (int64_t)split * o.slab_stride;
-        int64_t idx = n < o.wcols ? (int64_t)m * o.wcols + n : (int64_t)d.M * o.wcols + m;
-        b.p[o.space][base + idx] = acc;
-        break;
-    }
-    case OUT_PERMW_SLAB: {   // m = out feature, n = (a, b, c) | bias column
-        int64_t base = o.off + (int64_t)split * o.slab_stride;
-        int64_t idx;
+        if (bias) v += bias[n];
+        cbase[(unsigned)(m * o.ldc + n)] = act_fwd(o.act, v, n);
+    } else if constexpr (OK == OUT_ACCUM) {
+        cbase[(unsigned)(m * o.ldc + n)] += acc;
+    } else if constexpr (OK == OUT_CONV) {          // m = (p, octave), n = out channel -> x1[p, n*8 + octave]
+        cbase[(unsigned)((m >> 3) * o.ldc + n * NOCT + (m & 7))] = act_fwd(ACT_LEAKY, acc + bias[n], 0);
+    } else if constexpr (OK == OUT_SLAB) {
+        const unsigned idx = n < o.wcols ? (unsigned)(m * o.wcols + n) : (unsigned)(d.M * o.wcols + m);
+        cbase[(int64_t)split * o.slab_stride + idx] = acc;
+    } else {                                         // OUT_PERMW_SLAB: m = out feature, n = (a, b, c) | bias column
+        unsigned idx;
         if (n < o.wcols) {
             const int bc = o.pb * o.pc;
-            int a = n / bc, rem = n - a * bc;
-            int bb = rem / o.pc, c = rem - bb * o.pc;
-            idx = (int64_t)m * o.wcols + a * bc + c * o.pb + bb;
+            const int a = n / bc, rem = n - a * bc;
+            const int bb = rem / o.pc, c = rem - bb * o.pc;
+            idx = (unsigned)(m * o.wcols + a * bc + c * o.pb + bb);
         } else {
-            idx = (int64_t)d.M * o.wcols + m;
+            idx = (unsigned)(d.M * o.wcols + m);
         }
-        b.p[o.space][base + idx] = acc;
-        break;
-    }
+        cbase[(int64_t)split * o.slab_stride + idx] = acc;
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
-    const GemmDesc& d = descs[blockIdx.y];
+template <int AK, int BKIND, int OK>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
+    __shared__ float As[GEMM_BK][GEMM_BM + 4];
+    __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
+    const int tid = threadIdx.x;
+    const GemmDesc& d = descs[blockIdx.y];          // uniform: read through the scalar cache
     const int tiles_n = (d.N + GEMM_BN - 1) / GEMM_BN;
     const int tiles_m = (d.M + GEMM_BM - 1) / GEMM_BM;
     const int tile = blockIdx.x;
     const int split = blockIdx.z;
     if (tile >= tiles_m * tiles_n || split >= d.ksplit) return;   // block-uniform
+    const gcptr baseA = (gcptr)(b.p[d.A.space] + d.A.off);
+    const gcptr baseA2 = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
+    const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
     kchunk = (kchunk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
     const int k0 = split * kchunk;
     const int k1 = min(d.K, k0 + kchunk);
-
-    __shared__ float As[GEMM_BK][GEMM_BM + 4];
-    __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
-    const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     float acc[4][4];
 #pragma unroll
@@ -142,21 +137,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+    // per-thread tile coordinates: element e = tid + 256*i of a 64 x GEMM_BK tile
+    const bool akf = d.A.kfast != 0, bkf = d.B.kfast != 0;
+    constexpr int NL = GEMM_BM * GEMM_BK / 256;      // tile elements per lane and operand
+    float va[NL], ya[NL], vb[NL];
+    int cola[NL];
+
+#define GEMM_ISSUE(KT)                                                                                     \
+    {                                                                                                      \
+        Ld la[NL], lb[NL];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
+            const int e = tid + i * 256;                                                                   \
+            const int m = tm * GEMM_BM + (akf ? e / GEMM_BK : e % GEMM_BM);                                \
+            const int ka = (KT) + (akf ? e % GEMM_BK : e / GEMM_BM);                                       \
+            la[i] = addr_of<AK>(d.A, baseA, baseA2, m, ka, m < d.M && ka < k1);                            \
+            const int n = tn * GEMM_BN + (bkf ? e / GEMM_BK : e % GEMM_BN);                                \
+            const int kb = (KT) + (bkf ? e % GEMM_BK : e / GEMM_BN);                                       \
+            lb[i] = addr_of<BKIND>(d.B, baseB, baseB, kb, n, n < d.N && kb < k1);                          \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
+            va[i] = *la[i].p; cola[i] = la[i].col;                                                         \
+            if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ya[i] = *la[i].p2; else ya[i] = 1.f;    \
+            vb[i] = *lb[i].p;                                                                              \
+        }                                                                                                  \
+    }
+
+    if (k0 < k1) GEMM_ISSUE(k0)
     for (int kt = k0; kt < k1; kt += GEMM_BK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int e = tid + i * 256;
-            int ml, kl;
-            if (d.A.kfast) { ml = e / GEMM_BK; kl = e % GEMM_BK; } else { ml = e % GEMM_BM; kl = e / GEMM_BM; }
-            int m = tm * GEMM_BM + ml, k = kt + kl;
-            As[kl][ml] = (m < d.M && k < k1) ? fetch(d.A, b, m, k) : 0.f;
-            int nl;
-            if (d.B.kfast) { nl = e / GEMM_BK; kl = e % GEMM_BK; } else { nl = e % GEMM_BN; kl = e / GEMM_BN; }
-            int n = tn * GEMM_BN + nl;
-            k = kt + kl;
-            Bs[kl][nl] = (n < d.N && k < k1) ? fetch(d.B, b, k, n) : 0.f;
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            As[akf ? e % GEMM_BK : e / GEMM_BM][akf ? e / GEMM_BK : e % GEMM_BM] = finish<AK>(d.A, va[i], ya[i], cola[i]);
+            Bs[bkf ? e % GEMM_BK : e / GEMM_BN][bkf ? e / GEMM_BK : e % GEMM_BN] = vb[i];
         }
         __syncthreads();
+        if (kt + GEMM_BK < k1) GEMM_ISSUE(kt + GEMM_BK)      // next tile's loads fly under this tile's FMAs
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK; ++kk) {
             float a[4], bb[4];
@@ -169,66 +184,149 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ 
         }
         __syncthreads();
     }
+#undef GEMM_ISSUE
+    float* cbase = b.p[d.out.space] + d.out.off;
+    const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int m = tm * GEMM_BM + ty * 4 + i;
+        const int m = tm * GEMM_BM + ty * 4 + i;
         if (m >= d.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int n = tn * GEMM_BN + tx * 4 + j;
-            if (n < d.N) store_out(d, b, m, n, split, acc[i][j]);
+            const int n = tn * GEMM_BN + tx * 4 + j;
+            if (n < d.N) store_out<OK>(d, cbase, bias, m, n, split, acc[i][j]);
         }
     }
 }
 
-int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
+int gemm_variant(const GemmDesc& g) {
+    const int a = g.A.kind, bk = g.B.kind, o = g.out.kind;
+    if (a == OPK_DENSE && bk == OPK_DENSE && o == OUT_STORE) return GV_LIN_FWD;
+    if (a == OPK_DENSE && bk == OPK_PERMW && o == OUT_STORE) return GV_LIN_FWD_PERM;
+    if (a == OPK_ACTGRAD && bk == OPK_DENSE && o == OUT_SLAB) return GV_LIN_DW;
+    if (a == OPK_ACTGRAD && bk == OPK_DENSE && o == OUT_PERMW_SLAB) return GV_LIN_DW_PERM;
+    if (a == OPK_ACTGRAD && bk == OPK_DENSE && o == OUT_ACCUM) return GV_LIN_DA;
+    if (a == OPK_IM2COL && bk == OPK_PERMW && o == OUT_CONV) return GV_CONV_FWD;
+    if (a == OPK_CONVGRAD && bk == OPK_IM2COL && o == OUT_PERMW_SLAB) return GV_CONV_DW;
+    if (a == OPK_DENSE && bk == OPK_DENSE && o == OUT_SLAB) return GV_HH_DW;
+    return -1;
+}
+
+int launch_gemm(int variant, const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(gemm_kernel, dim3(max_tiles, count, max_split), dim3(256), 0, s, dev_descs, b);
+    const dim3 grid(max_tiles, count, max_split), block(256);
+#define GEMM_GO(A_, B_, O_) hipLaunchKernelGGL((gemm_kernel<A_, B_, O_>), grid, block, 0, s, dev_descs, b); break;
+    switch (variant) {
+    case GV_LIN_FWD: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_STORE)
+    case GV_LIN_FWD_PERM: GEMM_GO(OPK_DENSE, OPK_PERMW, OUT_STORE)
+    case GV_LIN_DW: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_SLAB)
+    case GV_LIN_DW_PERM: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB)
+    case GV_LIN_DA: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM)
+    case GV_CONV_FWD: GEMM_GO(OPK_IM2COL, OPK_PERMW, OUT_CONV)
+    case GV_CONV_DW: GEMM_GO(OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB)
+    case GV_HH_DW: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_SLAB)
+    default: return MST_ERR_UNSUPPORTED;
+    }
+#undef GEMM_GO
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Gather: materialise cat_with_broadcast (style/utils/pytorch.py:54-65) once for the Linears that
+// consume it — out[row, start_s + w] = seg_s[index_s(row), w], where index_s drops the row-space
+// dims the segment is broadcast over.  4 rows per workgroup (one wave each), lanes along the
+// concatenated feature axis (coalesced stores, broadcast/coalesced loads).  Its backward is the
+// segment reduce below applied to the gradient of the materialised tensor.
+__global__ __launch_bounds__(256) void gather_kernel(const GatherDesc* __restrict__ descs, Bases b) {
+    const GatherDesc& d = descs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wv; row < d.rows; row += gridDim.x * 4) {
+        unsigned t = (unsigned)row;
+        int rc[4];
+        rc[3] = t % (unsigned)d.d[3]; t /= (unsigned)d.d[3];
+        rc[2] = t % (unsigned)d.d[2]; t /= (unsigned)d.d[2];
+        rc[1] = t % (unsigned)d.d[1]; rc[0] = t / (unsigned)d.d[1];
+        float* out = b.p[SP_WS] + d.out_off + (int64_t)row * d.K;
+        for (int sIdx = 0; sIdx < d.nseg; ++sIdx) {
+            const Seg& sg = d.seg[sIdx];
+            const int srow = rc[0] * sg.s[0] + rc[1] * sg.s[1] + rc[2] * sg.s[2] + rc[3] * sg.s[3];
+            const float* src = b.p[sg.space] + sg.off + (int64_t)srow * sg.ld;
+            for (int w = lane; w < sg.width; w += 64) out[sg.start + w] = src[w];
+        }
+    }
+}
+
+int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipStream_t s) {
+    if (count <= 0) return 0;
+    int gx = (max_rows + 3) / 4;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(gather_kernel, dim3(gx, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
 // Segment reduce: the gradient of a broadcast segment of a concatenated input is the sum, over
 // the broadcast row-space dims, of its columns of dAcat (the backward of cat_with_broadcast's
-// expand, style/utils/pytorch.py:60-63).  One workgroup per destination row; 4 waves split the
-// reduced rows, 64 lanes walk the segment's columns (coalesced), fixed summation order.
+// expand, style/utils/pytorch.py:60-63).  Stage 1: one workgroup per (destination row, chunk of
+// 64 reduced rows) — 4 waves split the rows, 64 lanes walk the segment's columns (coalesced).
+// Segments reduced over <= 64 rows finish here (dst +=); wider ones leave per-chunk partials that
+// stage 2 sums in chunk order (deterministic; no float atomics).
+#define SEGRED_CHUNK 64
 __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
     const SegRedDesc& d = descs[blockIdx.y];
-    const int idx = blockIdx.x;
-    if (idx >= d.nidx) return;
+    if ((int)blockIdx.x >= d.nidx * d.nchunk) return;
+    const int idx = blockIdx.x / d.nchunk, chunk = blockIdx.x - idx * d.nchunk;
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    // kept coordinates of this destination row
     int kc[4], t = idx;
 #pragma unroll
     for (int q = 3; q >= 0; --q) { kc[q] = t % d.kd[q]; t /= d.kd[q]; }
     int rd[4], nred = 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rd[q] = d.kd[q] == 1 ? d.d[q] : 1; nred *= rd[q]; }
-    const float* src = b.p[SP_TMP] + d.src_off;
-    float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld;
+    const int r_begin = chunk * SEGRED_CHUNK, r_end = min(nred, r_begin + SEGRED_CHUNK);
+    const float* src = b.p[SP_GRAD] + d.src_off;
+    float* dst = d.nchunk == 1 ? b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld
+                               : b.p[SP_TMP] + d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width;
     for (int w0 = 0; w0 < d.width; w0 += 64) {
-        int w = w0 + lane;
+        const int w = w0 + lane;
         float acc = 0.f;
         if (w < d.width) {
-            for (int rr = grp; rr < nred; rr += 4) {
+            for (int rr = r_begin + grp; rr < r_end; rr += 4) {
                 int c[4], u = rr;
 #pragma unroll
                 for (int q = 3; q >= 0; --q) { c[q] = kc[q] + u % rd[q]; u /= rd[q]; }
-                int64_t row = (((int64_t)c[0] * d.d[1] + c[1]) * d.d[2] + c[2]) * d.d[3] + c[3];
+                const int64_t row = (((int64_t)c[0] * d.d[1] + c[1]) * d.d[2] + c[2]) * d.d[3] + c[3];
                 acc += src[row * d.src_ld + d.start + w];
             }
         }
         part[grp][lane] = acc;
         __syncthreads();
-        if (grp == 0 && w < d.width) dst[w] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (grp == 0 && w < d.width) {
+            const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            if (d.nchunk == 1) dst[w] += v; else dst[w] = v;
+        }
         __syncthreads();
     }
 }
 
-int launch_segred(const SegRedDesc* dev_descs, int count, int max_idx, Bases b, hipStream_t s) {
+__global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
+    const SegRedDesc& d = descs[blockIdx.y];
+    if (d.nchunk == 1) return;
+    const int total = d.nidx * d.width;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int idx = e / d.width, w = e - idx * d.width;
+        const float* pp = b.p[SP_TMP] + d.part_off + (int64_t)idx * d.nchunk * d.width + w;
+        float acc = 0.f;
+        for (int c = 0; c < d.nchunk; ++c) acc += pp[(int64_t)c * d.width];
+        b.p[SP_GRAD][d.dst_off + (int64_t)idx * d.dst_ld + w] += acc;
+    }
+}
+
+int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(segred_kernel, dim3(max_idx, count), dim3(256), 0, s, dev_descs, b);
+    hipLaunchKernelGGL(segred_kernel, dim3(max_blocks, count), dim3(256), 0, s, dev_descs, b);
+    if (stage2_blocks > 0) hipLaunchKernelGGL(segred2_kernel, dim3(stage2_blocks, count), dim3(256), 0, s, dev_descs, b);
     return (int)hipGetLastError();
 }
 
@@ -236,20 +334,23 @@ int launch_segred(const SegRedDesc* dev_descs, int count, int max_idx, Bases b, 
 // Deferred weight-gradient reduction: gpar[dst+i] += sum_s slab_s[i], splits summed in index
 // order (bitwise reproducible, unlike float atomics).  p.grad accumulates across iterations
 // exactly like loss.backward() does in train-model.py:126.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __restrict__ ents, Bases b) {
-    const SlabEntry& e = ents[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < e.count; i += gridDim.x * 256) {
-        const float* src = b.p[SP_TMP] + e.src + i;
-        float acc = 0.f;
-        for (int s = 0; s < e.splits; ++s) acc += src[(int64_t)s * e.stride];
-        b.p[SP_GPAR][e.dst + i] += acc;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __restrict__ ents, const SlabBlock* __restrict__ blocks, Bases b) {
+    const SlabBlock blk = blocks[blockIdx.x];       // 1024 consecutive elements of one entry
+    const SlabEntry& e = ents[blk.entry];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = blk.start + q * 256 + threadIdx.x;
+        if (i < e.count) {
+            const float* src = b.p[SP_TMP] + e.src + i;
+            float acc = 0.f;
+            for (int s = 0; s < e.splits; ++s) acc += src[(int64_t)s * e.stride];
+            b.p[SP_GPAR][e.dst + i] += acc;
+        }
     }
 }
 
-int launch_slab_reduce(const SlabEntry* dev, int count, int max_count, Bases b, hipStream_t s) {
-    if (count <= 0) return 0;
-    int gx = (max_count + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, count), dim3(256), 0, s, dev, b);
+int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s) {
+    if (nblocks <= 0) return 0;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblocks), dim3(256), 0, s, dev, blocks, b);
     return (int)hipGetLastError();
 }

@@ -3,10 +3,11 @@
 //
 // Loss = one streaming reduction over predictions/targets (7 partial sums per note tensor,
 // HBM-bound, coalesced, per-workgroup partials re-summed in order), a single-lane scalar tail
-// that evaluates the reference's loss tree on a tiny Wengert tape — so every data-dependent
-// Python branch of the reference (safe_div, safe_sqrt) is taken on the device with identical
-// values AND gradients, with no host sync — and one elementwise backward pass.  The tape
-// yields the full Jacobian d(leaf)/d(partial sum), so any loss leaf can be differentiated.
+// tail that evaluates the reference's loss tree with forward-mode dual numbers (16 lanes, one
+// per tape input) — so every data-dependent Python branch of the reference (safe_div, safe_sqrt)
+// is taken on the device with identical values AND gradients, with no host sync — and one
+// elementwise backward pass.  The tail yields the full Jacobian d(leaf)/d(partial sum), so any
+// loss leaf can be differentiated.
 #include "mst_common.h"
 
 #define LOSS_MAXBLK 256
@@ -78,66 +79,63 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, con
     }
 }
 
-// ------------------------------------------------------------------ scalar tail on a Wengert tape
-struct Tape {
-    float val[128], da[128], db[128];
-    short ia[128], ib[128];
-    int n;
-    __device__ int push(float v, int a, float pa, int b2, float pb) {
-        val[n] = v; ia[n] = (short)a; da[n] = pa; ib[n] = (short)b2; db[n] = pb;
-        return n++;
-    }
-    __device__ int input(float v) { return push(v, -1, 0.f, -1, 0.f); }
-    __device__ int add(int a, int b2) { return push(val[a] + val[b2], a, 1.f, b2, 1.f); }
-    __device__ int mul(int a, int b2) { return push(val[a] * val[b2], a, val[b2], b2, val[a]); }
-    __device__ int cmul(int a, float c) { return push(val[a] * c, a, c, -1, 0.f); }
-    __device__ int one_minus(int a) { return push(1.f - val[a], a, -1.f, -1, 0.f); }
-    __device__ int sqr(int a) { return push(val[a] * val[a], a, 2.f * val[a], -1, 0.f); }
-    __device__ int div(int a, int b2) {
-        const float d = val[b2];
-        return push(val[a] / d, a, 1.f / d, b2, -val[a] / (d * d));
-    }
-    __device__ int safe_div(int a, int b2) {          // style/model.py:854-860
-        float d = val[b2];
-        if (fabsf(d) < EPS_DIV) d = d < 0.f ? d - EPS_DIV : d + EPS_DIV;
-        return push(val[a] / d, a, 1.f / d, b2, -val[a] / (d * d));
-    }
-    __device__ int safe_sqrt(int a) {                 // style/utils/pytorch.py:68-71
-        if (val[a] == 0.f) return push(0.f, a, 0.f, -1, 0.f);
-        const float r = sqrtf(val[a]);
-        return push(r, a, 0.5f / r, -1, 0.f);
-    }
-    __device__ int tanh_(int a) { const float t = tanhf(val[a]); return push(t, a, 1.f - t * t, -1, 0.f); }
-    // quadratic mean with constant weights 1/k (get_mean, style/utils/pytorch.py:74-94)
-    __device__ int qmean2(int a, int b2) { return safe_sqrt(add(cmul(sqr(a), 0.5f), cmul(sqr(b2), 0.5f))); }
-    __device__ int qmean3(int a, int b2, int c) {
-        const float w = (float)(1.0 / 3.0);
-        return safe_sqrt(add(add(cmul(sqr(a), w), cmul(sqr(b2), w)), cmul(sqr(c), w)));
-    }
-};
+// ------------------------------------------------------------------ scalar tail, forward-mode AD
+// The reference's loss tree (style/model.py:847-997) evaluated with dual numbers: lane j (< 16)
+// carries d/d(input_j), so one pass over ~100 scalar ops yields every loss leaf AND the full
+// Jacobian d(leaf)/d(partial sum) — all in registers, no tape.  The reference's data-dependent
+// Python branches (safe_div, safe_sqrt) become value-dependent selects with identical values
+// and gradients.
+struct Dual { float v, d; };
+__device__ __forceinline__ Dual dl(float v, float d) { Dual r; r.v = v; r.d = d; return r; }
+__device__ __forceinline__ Dual d_add(Dual a, Dual b) { return dl(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual d_mul(Dual a, Dual b) { return dl(a.v * b.v, a.d * b.v + a.v * b.d); }
+__device__ __forceinline__ Dual d_cmul(Dual a, float c) { return dl(a.v * c, a.d * c); }
+__device__ __forceinline__ Dual d_one_minus(Dual a) { return dl(1.f - a.v, -a.d); }
+__device__ __forceinline__ Dual d_sqr(Dual a) { return dl(a.v * a.v, 2.f * a.v * a.d); }
+__device__ __forceinline__ Dual d_div(Dual a, Dual b) { const float q = a.v / b.v; return dl(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ Dual d_safe_div(Dual a, Dual b) {          // style/model.py:854-860
+    float den = b.v;
+    if (fabsf(den) < EPS_DIV) den = den < 0.f ? den - EPS_DIV : den + EPS_DIV;
+    const float q = a.v / den;
+    return dl(q, (a.d - q * b.d) / den);
+}
+__device__ __forceinline__ Dual d_safe_sqrt(Dual a) {                  // style/utils/pytorch.py:68-71
+    if (a.v == 0.f) return dl(0.f, 0.f);
+    const float r = sqrtf(a.v);
+    return dl(r, a.d * 0.5f / r);
+}
+__device__ __forceinline__ Dual d_tanh(Dual a) { const float t = tanhf(a.v); return dl(t, a.d * (1.f - t * t)); }
+// quadratic mean with constant weights 1/k (get_mean, style/utils/pytorch.py:74-94)
+__device__ __forceinline__ Dual d_qmean2(Dual a, Dual b) { return d_safe_sqrt(d_add(d_cmul(d_sqr(a), 0.5f), d_cmul(d_sqr(b), 0.5f))); }
+__device__ __forceinline__ Dual d_qmean3(Dual a, Dual b, Dual c) {
+    const float w = (float)(1.0 / 3.0);
+    return d_safe_sqrt(d_add(d_add(d_cmul(d_sqr(a), w), d_cmul(d_sqr(b), w)), d_cmul(d_sqr(c), w)));
+}
+
+struct ChannelLeaves { Dual total, notes, vel, dur, acc; };
 
 // channels losses of one note tensor from its partial sums (style/model.py:863-932)
-__device__ void channel_tree(Tape& tp, int base, bool pitched, bool normalize, int* leaf_total, int* leaf_notes,
-                             int* leaf_vel, int* leaf_dur, int* leaf_acc) {
-    const int TP = base, FP = base + 1, FN = base + 2, SEV = base + 3, SED = base + 4;
-    const int BCE = base + 5, NM = pitched ? base + 6 : base + 5;
-    const int prec = tp.safe_div(TP, tp.add(TP, FP));
-    const int rec = tp.safe_div(TP, tp.add(TP, FN));
-    const int f = tp.cmul(tp.safe_div(tp.mul(prec, rec), tp.add(prec, rec)), 2.f);
-    const int notes = tp.one_minus(f);
-    const int vel = tp.div(SEV, NM);
-    const int dur = tp.div(SED, NM);
+__device__ __forceinline__ ChannelLeaves channel_tree(const Dual* in, bool pitched, bool normalize) {
+    const Dual TP = in[0], FP = in[1], FN = in[2], SEV = in[3], SED = in[4];
+    const Dual NM = pitched ? in[6] : in[5];
+    ChannelLeaves o;
+    const Dual prec = d_safe_div(TP, d_add(TP, FP));
+    const Dual rec = d_safe_div(TP, d_add(TP, FN));
+    const Dual f = d_cmul(d_safe_div(d_mul(prec, rec), d_add(prec, rec)), 2.f);
+    o.notes = d_one_minus(f);
+    o.vel = d_div(SEV, NM);
+    o.dur = d_div(SED, NM);
     // first learn the right notes, then the right velocities: weights [notes, 1 - notes] are live
-    const int nv = tp.safe_sqrt(tp.add(tp.mul(notes, tp.sqr(notes)), tp.mul(tp.one_minus(notes), tp.sqr(vel))));
-    int total, acc = -1;
+    const Dual nv = d_safe_sqrt(d_add(d_mul(o.notes, d_sqr(o.notes)), d_mul(d_one_minus(o.notes), d_sqr(o.vel))));
     if (pitched) {
-        acc = tp.div(BCE, tp.cmul(NM, 3.f));
-        if (normalize) acc = tp.tanh_(acc);
-        total = tp.qmean3(dur, acc, nv);
+        o.acc = d_div(in[5], d_cmul(NM, 3.f));
+        if (normalize) o.acc = d_tanh(o.acc);
+        o.total = d_qmean3(o.dur, o.acc, nv);
     } else {
-        total = tp.qmean2(dur, nv);
+        o.acc = dl(0.f, 0.f);
+        o.total = d_qmean2(o.dur, nv);
     }
-    *leaf_total = total; *leaf_notes = notes; *leaf_vel = vel; *leaf_dur = dur; *leaf_acc = acc;
+    return o;
 }
 
 __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int nblk_p, int nblk_u, int has_u,
@@ -148,8 +146,8 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
     __shared__ float sums[N_TAPE_IN];
     const int tid = threadIdx.x;
     if (tid < 14) {
-        // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; the tape takes all 7 for the
-        // pitched tensor (inputs 0..6) and {TP FP FN SEvel SEdur Nmask} for the unpitched (7..12)
+        // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; inputs 0..6 are the pitched tensor's,
+        // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}
         const bool pitched = tid < 7;
         const int k = pitched ? tid : tid - 7;
         const float* src = scratch + (pitched ? 0 : LOSS_MAXBLK * 8);
@@ -178,47 +176,37 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
         sums[15] = db * db;
     }
     __syncthreads();
-    if (tid != 0) return;
-    Tape tp;
-    tp.n = 0;
-    for (int j = 0; j < N_TAPE_IN; ++j) tp.input(sums[j]);
-    int leaf[MST_N_LOSSES];
-    for (int k = 0; k < MST_N_LOSSES; ++k) leaf[k] = -1;
-    int dummy;
-    channel_tree(tp, 0, true, normalize != 0, &leaf[MST_L_P_TOTAL], &leaf[MST_L_P_NOTES], &leaf[MST_L_P_VELOCITY],
-                 &leaf[MST_L_P_DURATION], &leaf[MST_L_P_ACCIDENTALS]);
+    if (tid >= N_TAPE_IN) return;
+    Dual in[N_TAPE_IN];
+#pragma unroll
+    for (int j = 0; j < N_TAPE_IN; ++j) in[j] = dl(sums[j], j == tid ? 1.f : 0.f);
+    Dual leaf[MST_N_LOSSES];
+    bool present[MST_N_LOSSES];
+#pragma unroll
+    for (int k = 0; k < MST_N_LOSSES; ++k) { leaf[k] = dl(0.f, 0.f); present[k] = true; }
+    const ChannelLeaves p = channel_tree(in, true, normalize != 0);
+    leaf[MST_L_P_TOTAL] = p.total; leaf[MST_L_P_NOTES] = p.notes; leaf[MST_L_P_VELOCITY] = p.vel;
+    leaf[MST_L_P_DURATION] = p.dur; leaf[MST_L_P_ACCIDENTALS] = p.acc;
     if (has_u) {
-        channel_tree(tp, 7, false, normalize != 0, &leaf[MST_L_U_TOTAL], &leaf[MST_L_U_NOTES], &leaf[MST_L_U_VELOCITY],
-                     &leaf[MST_L_U_DURATION], &dummy);
-        leaf[MST_L_CH_TOTAL] = tp.qmean2(leaf[MST_L_P_TOTAL], leaf[MST_L_U_TOTAL]);
+        const ChannelLeaves u = channel_tree(in + 7, false, normalize != 0);
+        leaf[MST_L_U_TOTAL] = u.total; leaf[MST_L_U_NOTES] = u.notes; leaf[MST_L_U_VELOCITY] = u.vel;
+        leaf[MST_L_U_DURATION] = u.dur;
+        leaf[MST_L_CH_TOTAL] = d_qmean2(p.total, u.total);
     } else {
-        leaf[MST_L_CH_TOTAL] = leaf[MST_L_P_TOTAL];
+        present[MST_L_U_TOTAL] = present[MST_L_U_NOTES] = present[MST_L_U_VELOCITY] = present[MST_L_U_DURATION] = false;
+        leaf[MST_L_CH_TOTAL] = p.total;
     }
-    int li = 13, lm = 14;
-    if (normalize) { li = tp.tanh_(13); lm = tp.tanh_(14); }
+    Dual li = in[13], lm = in[14];
+    if (normalize) { li = d_tanh(li); lm = d_tanh(lm); }
     leaf[MST_L_SI_INSTRUMENTS] = li;
     leaf[MST_L_SI_MODE] = lm;
-    leaf[MST_L_SI_BPM] = 15;
-    leaf[MST_L_SI_TOTAL] = tp.qmean3(li, lm, 15);
-    leaf[MST_L_TOTAL] = tp.qmean2(leaf[MST_L_CH_TOTAL], leaf[MST_L_SI_TOTAL]);
-
-    float adj[128];
+    leaf[MST_L_SI_BPM] = in[15];
+    leaf[MST_L_SI_TOTAL] = d_qmean3(li, lm, in[15]);
+    leaf[MST_L_TOTAL] = d_qmean2(leaf[MST_L_CH_TOTAL], leaf[MST_L_SI_TOTAL]);
+#pragma unroll
     for (int k = 0; k < MST_N_LOSSES; ++k) {
-        if (leaf[k] < 0) {
-            losses[k] = __builtin_nanf("");
-            for (int j = 0; j < N_TAPE_IN; ++j) saved[SAVED_J + k * N_TAPE_IN + j] = 0.f;
-            continue;
-        }
-        losses[k] = tp.val[leaf[k]];
-        for (int q = 0; q < tp.n; ++q) adj[q] = 0.f;
-        adj[leaf[k]] = 1.f;
-        for (int q = tp.n - 1; q >= N_TAPE_IN; --q) {
-            const float a = adj[q];
-            if (a == 0.f) continue;
-            if (tp.ia[q] >= 0) adj[tp.ia[q]] += a * tp.da[q];
-            if (tp.ib[q] >= 0) adj[tp.ib[q]] += a * tp.db[q];
-        }
-        for (int j = 0; j < N_TAPE_IN; ++j) saved[SAVED_J + k * N_TAPE_IN + j] = adj[j];
+        if (tid == 0) losses[k] = present[k] ? leaf[k].v : __builtin_nanf("");
+        saved[SAVED_J + k * N_TAPE_IN + tid] = present[k] ? leaf[k].d : 0.f;
     }
 }
 

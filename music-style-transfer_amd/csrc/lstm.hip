@@ -2,14 +2,21 @@
 // order i,f,g,o; zero initial state; one layer).  The input projection x W_ih^T + b_ih is a
 // plain GEMM (gemm.hip); only the strictly sequential part lives here.
 //
-// One workgroup per sequence, one lane per gate row (4H <= 1024).  For H <= 64 every lane keeps
-// its W_hh row in VGPRs for the whole sequence and h_{t-1} is broadcast from LDS, so a step is
-// 64 FMAs + two barriers with no global traffic except the streamed zx/gate rows.  Wider
-// hidden states (StyleEncoder, H = 192) re-read W_hh from L2 each step.
-// The backward kernel runs BPTT with W_hh read coalesced along the hidden index.
+// One workgroup per sequence.  H <= 64: one lane per gate row, its W_hh row (forward) or W_hh
+// column slice (backward) lives in VGPRs for the whole sequence, h_{t-1} / dz_t are broadcast
+// from LDS, and the streamed per-step operands (zx row, saved gates) are prefetched one step
+// ahead so a step costs two barriers and no exposed memory latency.  H > 64 (StyleEncoder,
+// H = 192, 590 KB of W_hh — more than one CU's registers + LDS): one lane per gate row over W_hh^T (
+// transposed once per forward so the per-step L2 reads are lane-contiguous); every in-loop barrier
+// is LDS-only (MST_LDS_BARRIER), so streamed stores / prefetches never stall a step.
 #include "mst_common.h"
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 template <bool REG>
 __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
@@ -24,12 +31,17 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
     float* ws = b.p[SP_WS];
     float* tmp = b.p[SP_TMP];
     float w[REG ? 64 : 1];
-    float bias = 0.f;
-    if (tid < G) {
-        bias = b.p[SP_PAR][d.bhh_off + tid];
-        if (REG) {
+    if (REG && tid < G) {
 #pragma unroll
-            for (int k = 0; k < 64; ++k) w[k] = k < H ? whh[(int64_t)tid * H + k] : 0.f;
+        for (int k = 0; k < 64; ++k) w[k] = k < H ? whh[(int64_t)tid * H + k] : 0.f;
+    }
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, zq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = d.reverse ? d.S - 1 : 0;
+    if (tid < H) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bias[q] = b.p[SP_PAR][d.bhh_off + q * H + tid];
+            zq[q] = zx[((int64_t)bi * d.S + s0) * G + q * H + tid];
         }
     }
     if (tid < 256) h_s[tid] = 0.f;
@@ -37,34 +49,53 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
     for (int step = 0; step < d.S; ++step) {
         const int s = d.reverse ? d.S - 1 - step : step;
         const int64_t row = (int64_t)bi * d.S + s;
-        __syncthreads();
-        if (tid < G) {
-            float z = zx[row * G + tid] + bias;
-            if (REG) {
+        float zn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tid < H && step + 1 < d.S) {                    // next step's zx row: in flight under this step's matvec
+            const int sn = d.reverse ? s - 1 : s + 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zn[q] = zx[((int64_t)bi * d.S + sn) * G + q * H + tid];
+        }
+        MST_LDS_BARRIER();
+        if (REG) {
+            if (tid < G) {
+                float z = 0.f;
 #pragma unroll
                 for (int k = 0; k < 64; ++k) z = fmaf(w[k], h_s[k], z);
-            } else {
-                const float* wr = whh + (int64_t)tid * H;
-                for (int k = 0; k < H; ++k) z = fmaf(wr[k], h_s[k], z);
+                z_s[tid] = z;
             }
-            z_s[tid] = z;
+        } else if (tid < G) {
+            // thread per gate row over the transposed copy: lane-contiguous (coalesced) reads, 4 chains
+            const float* wt = tmp + d.whht_off + tid;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = 0;
+            for (; k + 4 <= H; k += 4) {
+                a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
+                a1 = fmaf(wt[(int64_t)(k + 1) * G], h_s[k + 1], a1);
+                a2 = fmaf(wt[(int64_t)(k + 2) * G], h_s[k + 2], a2);
+                a3 = fmaf(wt[(int64_t)(k + 3) * G], h_s[k + 3], a3);
+            }
+            for (; k < H; ++k) a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
+            z_s[tid] = (a0 + a1) + (a2 + a3);
         }
-        __syncthreads();
+        MST_LDS_BARRIER();
         if (tid < H) {
-            float ig = sigm(z_s[tid]), fg = sigm(z_s[H + tid]);
-            float gg = tanhf(z_s[2 * H + tid]), og = sigm(z_s[3 * H + tid]);
+            const float ig = sigm(z_s[tid] + zq[0] + bias[0]), fg = sigm(z_s[H + tid] + zq[1] + bias[1]);
+            const float gg = tanhf(z_s[2 * H + tid] + zq[2] + bias[2]), og = sigm(z_s[3 * H + tid] + zq[3] + bias[3]);
             tmp[d.hprev_off + row * H + tid] = h_s[tid];
             c = fg * c + ig * gg;
-            float h = og * tanhf(c);
+            const float h = og * tanhf(c);
             float* g = tmp + d.gates_off + row * G;
             g[tid] = ig; g[H + tid] = fg; g[2 * H + tid] = gg; g[3 * H + tid] = og;
             tmp[d.c_off + row * H + tid] = c;
             ws[d.out_off + row * d.out_ld + tid] = h;
             h_s[tid] = h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
         }
     }
 }
 
+template <bool REG>
 __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
     const LstmDesc& d = descs[blockIdx.y];
     const int bi = blockIdx.x;
@@ -76,41 +107,100 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* tmp = b.p[SP_TMP];
     float* gr = b.p[SP_GRAD];
+    const int kk = tid % H, part = tid / H;                 // lane (part, kk) sums W_hh[part*H + jj, kk] dz[part*H + jj]
+    float w[REG ? 64 : 1];
+    if (REG && tid < G) {
+#pragma unroll
+        for (int jj = 0; jj < 64; ++jj) w[jj] = jj < H ? whh[((int64_t)part * H + jj) * H + kk] : 0.f;
+    }
     if (tid < 256) dh_next[tid] = 0.f;
     float dc_next = 0.f;
+    // streamed operands of a step (saved gates, cell states, incoming gradient), prefetched one step ahead
+    float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define LSTM_LOAD(STEP, DST)                                                                            \
+    {                                                                                                   \
+        const int s_ = d.reverse ? d.S - 1 - (STEP) : (STEP);                                           \
+        const int sp_ = d.reverse ? s_ + 1 : s_ - 1;                                                    \
+        const int64_t row_ = (int64_t)bi * d.S + s_;                                                    \
+        const float* g_ = tmp + d.gates_off + row_ * G;                                                 \
+        DST[0] = g_[tid]; DST[1] = g_[H + tid]; DST[2] = g_[2 * H + tid]; DST[3] = g_[3 * H + tid];     \
+        DST[4] = tmp[d.c_off + row_ * H + tid];                                                         \
+        DST[5] = (STEP) > 0 ? tmp[d.c_off + ((int64_t)bi * d.S + sp_) * H + tid] : 0.f;                 \
+        DST[6] = gr[d.gout_off + row_ * d.out_ld + tid];                                                \
+    }
+    if (tid < H) LSTM_LOAD(d.S - 1, sv)
     __syncthreads();
     for (int step = d.S - 1; step >= 0; --step) {
         const int s = d.reverse ? d.S - 1 - step : step;
-        const int sp = d.reverse ? s + 1 : s - 1;          // sequence position of the previous step
         const int64_t row = (int64_t)bi * d.S + s;
+        float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tid < H) {
-            const float* g = tmp + d.gates_off + row * G;
-            float ig = g[tid], fg = g[H + tid], gg = g[2 * H + tid], og = g[3 * H + tid];
-            float c = tmp[d.c_off + row * H + tid];
-            float cprev = step > 0 ? tmp[d.c_off + ((int64_t)bi * d.S + sp) * H + tid] : 0.f;
-            float dh = gr[d.gout_off + row * d.out_ld + tid] + dh_next[tid];
-            float tc = tanhf(c);
-            float dc = dc_next + dh * og * (1.f - tc * tc);
-            float dzi = dc * gg * ig * (1.f - ig);
-            float dzf = dc * cprev * fg * (1.f - fg);
-            float dzg = dc * ig * (1.f - gg * gg);
-            float dzo = dh * tc * og * (1.f - og);
+            if (step > 0) LSTM_LOAD(step - 1, nx)
+            const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], c = sv[4], cprev = sv[5];
+            const float dh = sv[6] + dh_next[tid];
+            const float tc = tanhf(c);
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float dzi = dc * gg * ig * (1.f - ig);
+            const float dzf = dc * cprev * fg * (1.f - fg);
+            const float dzg = dc * ig * (1.f - gg * gg);
+            const float dzo = dh * tc * og * (1.f - og);
             dc_next = dc * fg;
             dz_s[tid] = dzi; dz_s[H + tid] = dzf; dz_s[2 * H + tid] = dzg; dz_s[3 * H + tid] = dzo;
             float* gz = gr + d.gzx_off + row * G;
             gz[tid] = dzi; gz[H + tid] = dzf; gz[2 * H + tid] = dzg; gz[3 * H + tid] = dzo;
         }
-        __syncthreads();
+        MST_LDS_BARRIER();
         if (tid < G) {   // dh_{t-1}[k] = sum_j W_hh[j,k] dz[j], four partial sums per k
-            const int k = tid % H, part = tid / H;
             float acc = 0.f;
-            for (int j = part * H; j < (part + 1) * H; ++j) acc = fmaf(whh[(int64_t)j * H + k], dz_s[j], acc);
+            if (REG) {
+#pragma unroll
+                for (int jj = 0; jj < 64; ++jj) acc = fmaf(w[jj], dz_s[min(part * H + jj, G - 1)], acc);
+            } else {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const float* wc = whh + (int64_t)part * H * H + kk;      // coalesced along kk
+                const float* dzp = dz_s + part * H;
+                int jj = 0;
+                for (; jj + 4 <= H; jj += 4) {
+                    a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
+                    a1 = fmaf(wc[(int64_t)(jj + 1) * H], dzp[jj + 1], a1);
+                    a2 = fmaf(wc[(int64_t)(jj + 2) * H], dzp[jj + 2], a2);
+                    a3 = fmaf(wc[(int64_t)(jj + 3) * H], dzp[jj + 3], a3);
+                }
+                for (; jj < H; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
+                acc = (a0 + a1) + (a2 + a3);
+            }
             red_s[tid] = acc;
         }
-        __syncthreads();
-        if (tid < H) dh_next[tid] = (red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]);
-        __syncthreads();
+        MST_LDS_BARRIER();
+        if (tid < H) {
+            dh_next[tid] = (red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) sv[q] = nx[q];     // the prefetch landed under the matvec above
+        }
+        MST_LDS_BARRIER();
     }
+#undef LSTM_LOAD
+}
+
+// W_hh (4H x H) -> W_hh^T (H x 4H) so that the H > 64 forward reads it lane-contiguously
+__global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc& d = descs[blockIdx.y];
+    if (d.H <= 64) return;
+    const int G = 4 * d.H, n = G * d.H;
+    const float* w = b.p[SP_PAR] + d.whh_off;
+    float* wt = b.p[SP_TMP] + d.whht_off;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int k = e / G, j = e - k * G;       // consecutive lanes write consecutive j
+        wt[e] = w[(int64_t)j * d.H + k];
+    }
+}
+
+int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s) {
+    if (count <= 0 || maxH <= 64) return 0;
+    int nb = (4 * maxH * maxH + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(lstm_transpose_kernel, dim3(nb, count), dim3(256), 0, s, dev_descs, b);
+    return (int)hipGetLastError();
 }
 
 static int block_for(int maxH) {
@@ -129,6 +219,9 @@ int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Ba
 
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
+    if (maxH <= 64)
+        hipLaunchKernelGGL((lstm_bwd_kernel<true>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
+    else
+        hipLaunchKernelGGL((lstm_bwd_kernel<false>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
     return (int)hipGetLastError();
 }

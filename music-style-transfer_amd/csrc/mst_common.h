@@ -5,6 +5,19 @@
 
 #include "../../include/mst_amd.h"
 
+// global-address-space qualifier for hot loads (so they are global_load, never flat_load);
+// the hipsim interpreter pre-defines it as nothing
+#ifndef MST_GLOBAL_AS
+#define MST_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, then s_barrier.  Unlike
+// __syncthreads() it does not drain vmcnt, so global prefetches / streamed stores issued around
+// it stay in flight (on MI355X the vmcnt(0) of __syncthreads() cost ~1-4 us per LSTM step).
+// Only for data exchanged through LDS; the interpreter maps it to its ordinary barrier.
+#ifndef MST_LDS_BARRIER
+#define MST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // ---- piano-roll constants (style/model.py:13-25)
 #define NF 10       // beat fractions
 #define NPF 5       // pitched note features
@@ -64,14 +77,24 @@ struct GemmDesc {
     OutSpec out;
 };
 
+// ---- gather: out[row, :] = concat_s seg_s[index_s(row), :]   (cat_with_broadcast, materialised once)
+struct GatherDesc {
+    int32_t rows, K, nseg;
+    int32_t d[4];
+    int64_t out_off;     // [SP_WS] rows x K contiguous
+    Seg seg[MAX_SEG];
+};
+
 // ---- segment reduce: dX_seg[idx, w] += sum_{rows -> idx} dAcat[row, start + w]
 struct SegRedDesc {
-    int64_t src_off; int32_t src_ld; int32_t start, width;   // dAcat in SP_TMP
+    int64_t src_off; int32_t src_ld; int32_t start, width;   // gradient of the gathered tensor, SP_GRAD
     int64_t dst_off; int32_t dst_ld;                           // gradient slot in SP_GRAD
     int32_t d[4];        // row-space dims
     int32_t s[4];        // destination row stride per dim (0 = reduced)
     int32_t nidx;        // number of distinct destination rows
     int32_t kd[4];       // kept-dim sizes (1 where reduced)
+    int32_t nchunk;      // chunks of 64 reduced rows; > 1 => partials at part_off, summed by stage 2
+    int64_t part_off;    // [SP_TMP] nidx * nchunk * width
 };
 
 // ---- LSTM recurrence
@@ -83,6 +106,7 @@ struct LstmDesc {
     int64_t gates_off, c_off, hprev_off;                                  // saved (B*S,4H),(B*S,H),(B*S,H)
     int64_t gout_off;    // gradient of out (same ld)                      [SP_WS]
     int64_t gzx_off;     // gradient of zx, written (=)
+    int64_t whht_off;    // [SP_TMP] W_hh transposed (H x 4H), built per forward when H > 64
 };
 
 // ---- combine (style/model.py:796-815): out = sum_c x_c n_c / sum_c n_c
@@ -113,6 +137,7 @@ struct NotesDesc {
 
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
 struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; };
+struct SlabBlock { int32_t entry, start; };   // one workgroup's 1024-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)
 struct Sizes {
@@ -133,8 +158,12 @@ struct Sizes {
 Sizes mst_sizes(const mst_dims& d);
 
 // ---- launchers (each returns a hipError_t-style int; 0 = ok)
-int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s);
-int launch_segred(const SegRedDesc* dev_descs, int count, int max_idx, Bases b, hipStream_t s);
+enum { GV_LIN_FWD, GV_LIN_FWD_PERM, GV_LIN_DW, GV_LIN_DW_PERM, GV_LIN_DA, GV_CONV_FWD, GV_CONV_DW, GV_HH_DW };
+int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipStream_t s);
+int gemm_variant(const GemmDesc& g);
+int launch_gemm(int variant, const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s);
+int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s);
+int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_combine_fwd(const CombineDesc* dev_desc, const CombineDesc& host, Bases b, hipStream_t s);
@@ -143,9 +172,9 @@ int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hi
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
 int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
-int launch_slab_reduce(const SlabEntry* dev, int count, int max_count, Bases b, hipStream_t s);
+int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s);
 bool notes_widths_supported(int W, int CW, int ML);
 
 #define GEMM_BM 64
 #define GEMM_BN 64
-#define GEMM_BK 16
+#define GEMM_BK 32

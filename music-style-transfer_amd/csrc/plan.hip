@@ -185,7 +185,7 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 // ------------------------------------------------------------------------------------------ plan
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
-enum { K_GEMM, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B };
+enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T };
 struct Step { int kind, first, count, a, b; };
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
@@ -193,15 +193,15 @@ static int stage_idx(int stage) { return stage == MST_STAGE_EXTRACT ? 0 : stage 
 
 struct mst_plan {
     mst_dims d; Sizes z; ParamTable pt;
-    std::vector<GemmDesc> gemms; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
+    std::vector<GemmDesc> gemms; std::vector<GatherDesc> gathers; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
     std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<SlabEntry> slabs[3];
     std::vector<Op> ops;
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
-    GemmDesc* d_gemms = nullptr; SegRedDesc* d_segreds = nullptr; LstmDesc* d_lstms = nullptr;
+    GemmDesc* d_gemms = nullptr; GatherDesc* d_gathers = nullptr; SegRedDesc* d_segreds = nullptr; LstmDesc* d_lstms = nullptr;
     CombineDesc* d_combines = nullptr; NotesDesc* d_notes = nullptr; SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
-    int slab_max[3] = {0, 0, 0};
+    std::vector<SlabBlock> slab_blocks[3]; SlabBlock* d_slab_blocks[3] = {nullptr, nullptr, nullptr};
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     int err = 0;
 
@@ -217,7 +217,8 @@ struct mst_plan {
     }
     int64_t tmp(int64_t n) { int64_t o = tmp_top; tmp_top += align(n); return o; }
     static int tiles(int M, int N) { return ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN); }
-    static int splits_for(int K) { int s = K / 256; return s < 1 ? 1 : (s > 128 ? 128 : s); }
+    // weight-gradient GEMMs reduce over rows: one k-split per 64 rows (2 k-tiles), capped at 256 slabs
+    static int splits_for(int K) { int s = (K + 63) / 64; return s < 1 ? 1 : (s > 256 ? 256 : s); }
 
     static SegIn seg(const T& t, int s0, int s1, int s2, int s3, bool grad = true) {
         return SegIn{SP_WS, t.off, t.ld, t.cols, {s0, s1, s2, s3}, grad};
@@ -226,33 +227,72 @@ struct mst_plan {
         return SegIn{space, 0, ld, width, {s0, s1, s2, s3}, false};
     }
 
-    void fill_cat(Operand& o, const int rs[4], const std::vector<SegIn>& segs, int ones_at, int kfast) {
-        o.kind = OPK_CAT; o.nseg = (int)segs.size(); o.d1 = rs[1]; o.d2 = rs[2]; o.d3 = rs[3];
-        o.ones_at = ones_at; o.kfast = kfast;
+    // cat_with_broadcast (style/utils/pytorch.py:54-65) of several sources, materialised once.
+    // forward: gather kernel; backward: segment-reduce of the concat's gradient into each source.
+    T gather(int stage, const int rs[4], const std::vector<SegIn>& segs) {
+        if (segs.size() > MAX_SEG) err = MST_ERR_UNSUPPORTED;
+        const int rows = rs[0] * rs[1] * rs[2] * rs[3];
+        int K = 0;
+        for (auto& s : segs) K += s.width;
+        T out = newT(rows, K);
+        GatherDesc g{}; g.rows = rows; g.K = K; g.nseg = (int)segs.size(); g.out_off = out.off;
+        for (int q = 0; q < 4; ++q) g.d[q] = rs[q];
         int start = 0;
         for (size_t i = 0; i < segs.size(); ++i) {
-            Seg& s = o.seg[i];
+            Seg& s = g.seg[i];
             s.space = segs[i].space; s.off = segs[i].off; s.ld = segs[i].ld; s.start = start; s.width = segs[i].width;
             for (int q = 0; q < 4; ++q) s.s[q] = segs[i].s[q];
             start += segs[i].width;
         }
+        Op op; op.stage = stage;
+        op.fwd.push_back(Step{K_GATHER, (int)gathers.size(), 1, rows, 0});
+        gathers.push_back(g);
+        int first = (int)segreds.size(), cnt = 0, maxidx = 1, stage2 = 0;
+        start = 0;
+        for (auto& s : segs) {
+            if (s.grad) {
+                SegRedDesc r{}; r.src_off = out.off; r.src_ld = K; r.start = start; r.width = s.width;
+                r.dst_off = s.off; r.dst_ld = s.ld; r.nidx = 1;
+                for (int q = 0; q < 4; ++q) {
+                    r.d[q] = rs[q]; r.s[q] = s.s[q];
+                    r.kd[q] = (s.s[q] != 0 && rs[q] > 1) ? rs[q] : 1;
+                    r.nidx *= r.kd[q];
+                }
+                // destination rows must be the natural row-major index of the kept dims
+                int nat = 1;
+                for (int q = 3; q >= 0; --q) {
+                    if (r.kd[q] > 1) { if (s.s[q] != nat) err = MST_ERR_UNSUPPORTED; nat *= r.kd[q]; }
+                }
+                int nred = 1;
+                for (int q = 0; q < 4; ++q) if (r.kd[q] == 1) nred *= rs[q];
+                r.nchunk = (nred + 63) / 64;
+                if (r.nchunk > 1) {
+                    r.part_off = tmp((int64_t)r.nidx * r.nchunk * r.width);
+                    const int b2 = (r.nidx * r.width + 255) / 256;
+                    if (b2 > stage2) stage2 = b2;
+                }
+                if (r.nidx * r.nchunk > maxidx) maxidx = r.nidx * r.nchunk;
+                segreds.push_back(r); ++cnt;
+            }
+            start += s.width;
+        }
+        if (cnt) op.bwd.push_back(Step{K_SEGRED, first, cnt, maxidx, stage2});
+        ops.push_back(op);
+        return out;
     }
 
-    // cat_with_broadcast + nn.Linear (+ activation); emits forward GEMM, weight-gradient GEMM (k-split
-    // slabs) and, when any source needs a gradient, the input-gradient GEMM + per-source reductions.
-    T linear(int stage, const int rs[4], const std::vector<SegIn>& segs, const std::string& wname,
+    // nn.Linear (+ activation) on a dense (rows x K, row stride ld) input that lives in `space`.
+    // Emits the forward GEMM, the k-split weight|bias-gradient GEMM and, when the input needs a
+    // gradient, the input-gradient GEMM accumulating straight into the input's gradient slot.
+    T linear(int stage, int space, int64_t xoff, int xld, int rows, int K, bool xgrad, const std::string& wname,
              const std::string& bname, int N, int act, const T* out_opt = nullptr, int pb = 0, int pc = 0,
              const char* name = nullptr) {
-        if (segs.size() > MAX_SEG) { err = MST_ERR_UNSUPPORTED; }
-        const int rows = rs[0] * rs[1] * rs[2] * rs[3];
-        int K = 0;
-        for (auto& s : segs) K += s.width;
         T out = out_opt ? *out_opt : newT(rows, N, name);
         const int64_t woff = pt.off(wname), boff = pt.off(bname);
         Op op; op.stage = stage;
         {
             GemmDesc g{}; g.M = rows; g.N = N; g.K = K; g.ksplit = 1;
-            fill_cat(g.A, rs, segs, -1, 1);
+            g.A.kind = OPK_DENSE; g.A.space = space; g.A.off = xoff; g.A.si = xld; g.A.sj = 1; g.A.ones_at = -1; g.A.kfast = 1;
             if (pb) { g.B.kind = OPK_PERMW; g.B.space = SP_PAR; g.B.off = woff; g.B.ld = K; g.B.pb = pb; g.B.pc = pc; g.B.kfast = 1; }
             else { g.B.kind = OPK_DENSE; g.B.space = SP_PAR; g.B.off = woff; g.B.si = 1; g.B.sj = K; g.B.ones_at = -1; g.B.kfast = 1; }
             g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = act; g.out.off = out.off;
@@ -260,11 +300,11 @@ struct mst_plan {
             op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
             gemms.push_back(g);
         }
-        {   // dW | db
+        {   // dW | db  =  (dY o act')^T [X | 1]
             GemmDesc w{}; w.M = N; w.N = K + 1; w.K = rows; w.ksplit = splits_for(rows);
             w.A.kind = OPK_ACTGRAD; w.A.space = SP_GRAD; w.A.off = out.off; w.A.space2 = SP_WS; w.A.off2 = out.off;
             w.A.ld = out.ld; w.A.act = act; w.A.transposed = 1; w.A.kfast = 0;
-            fill_cat(w.B, rs, segs, K, 0);
+            w.B.kind = OPK_DENSE; w.B.space = space; w.B.off = xoff; w.B.si = xld; w.B.sj = 1; w.B.ones_at = K; w.B.kfast = 0;
             const int64_t stride = (int64_t)N * K + N;
             const int64_t slab = tmp(stride * w.ksplit);
             w.out.kind = pb ? OUT_PERMW_SLAB : OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride;
@@ -274,58 +314,21 @@ struct mst_plan {
             slabs[stage_idx(stage)].push_back(SlabEntry{woff, slab, stride, N * K, w.ksplit});
             slabs[stage_idx(stage)].push_back(SlabEntry{boff, slab + (int64_t)N * K, stride, N, w.ksplit});
         }
-        bool any_grad = false;
-        for (auto& s : segs) any_grad |= s.grad;
-        if (any_grad) {
-            if (pb) { err = MST_ERR_UNSUPPORTED; }
-            // one source whose rows are exactly the output rows: accumulate straight into its gradient
-            bool single = segs.size() == 1;
-            if (single) {
-                int nat = 1;
-                for (int q = 3; q >= 0; --q) {
-                    if (rs[q] > 1 && segs[0].s[q] != nat) single = false;
-                    nat *= rs[q];
-                }
-            }
+        if (xgrad) {
+            if (pb || space != SP_WS) { err = MST_ERR_UNSUPPORTED; }
             GemmDesc a{}; a.M = rows; a.N = K; a.K = N; a.ksplit = 1;
             a.A.kind = OPK_ACTGRAD; a.A.space = SP_GRAD; a.A.off = out.off; a.A.space2 = SP_WS; a.A.off2 = out.off;
             a.A.ld = out.ld; a.A.act = act; a.A.transposed = 0; a.A.kfast = 1;
             a.B.kind = OPK_DENSE; a.B.space = SP_PAR; a.B.off = woff; a.B.si = K; a.B.sj = 1; a.B.ones_at = -1; a.B.kfast = 0;
-            a.out.bias_space = -1; a.out.act = ACT_NONE;
-            if (single) {
-                a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = segs[0].off; a.out.ldc = segs[0].ld;
-                op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
-                gemms.push_back(a);
-            } else {
-                const int64_t dacat = tmp((int64_t)rows * K);
-                a.out.kind = OUT_STORE; a.out.space = SP_TMP; a.out.off = dacat; a.out.ldc = K;
-                op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
-                gemms.push_back(a);
-                int first = (int)segreds.size(), cnt = 0, maxidx = 1, start = 0;
-                for (auto& s : segs) {
-                    if (s.grad) {
-                        SegRedDesc r{}; r.src_off = dacat; r.src_ld = K; r.start = start; r.width = s.width;
-                        r.dst_off = s.off; r.dst_ld = s.ld; r.nidx = 1;
-                        for (int q = 0; q < 4; ++q) {
-                            r.d[q] = rs[q]; r.s[q] = s.s[q];
-                            r.kd[q] = (s.s[q] != 0 && rs[q] > 1) ? rs[q] : 1;
-                            r.nidx *= r.kd[q];
-                        }
-                        // destination rows must be the natural row-major index of the kept dims
-                        int nat = 1;
-                        for (int q = 3; q >= 0; --q) {
-                            if (r.kd[q] > 1) { if (s.s[q] != nat) err = MST_ERR_UNSUPPORTED; nat *= r.kd[q]; }
-                        }
-                        if (r.nidx > maxidx) maxidx = r.nidx;
-                        segreds.push_back(r); ++cnt;
-                    }
-                    start += s.width;
-                }
-                op.bwd.push_back(Step{K_SEGRED, first, cnt, maxidx, 0});
-            }
+            a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = xoff; a.out.ldc = xld; a.out.bias_space = -1; a.out.act = ACT_NONE;
+            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
+            gemms.push_back(a);
         }
         ops.push_back(op);
         return out;
+    }
+    T linear(int stage, const T& x, bool xgrad, const std::string& pre, int N, int act, const char* name = nullptr) {
+        return linear(stage, SP_WS, x.off, x.ld, x.rows, x.cols, xgrad, pre + ".weight", pre + ".bias", N, act, nullptr, 0, 0, name);
     }
 
     // Conv1d(50 -> OC, k=14, s=7, p=4) over the note axis + leaky, as implicit-im2col GEMM (style/model.py:46-53,78-84)
@@ -360,10 +363,10 @@ struct mst_plan {
     }
 
     // one LSTM direction: input projection (a linear op) + the recurrence op
-    void lstm(int stage, const int rs[4], const std::vector<SegIn>& xsegs, int B, int S, int H, int reverse,
-              const std::string& pre, const T& out, int coloff) {
+    void lstm(int stage, const T& x, int B, int S, int H, int reverse, const std::string& pre, const T& out, int coloff) {
         const std::string sfx = reverse ? "_reverse" : "";
-        T zx = linear(stage, rs, xsegs, pre + ".weight_ih_l0" + sfx, pre + ".bias_ih_l0" + sfx, 4 * H, ACT_NONE);
+        T zx = linear(stage, SP_WS, x.off, x.ld, x.rows, x.cols, true, pre + ".weight_ih_l0" + sfx, pre + ".bias_ih_l0" + sfx,
+                      4 * H, ACT_NONE);
         if (4 * H > 1024) err = MST_ERR_UNSUPPORTED;
         const int64_t whh = pt.off(pre + ".weight_hh_l0" + sfx), bhh = pt.off(pre + ".bias_hh_l0" + sfx);
         const int64_t n = (int64_t)B * S;
@@ -372,6 +375,8 @@ struct mst_plan {
         l.out_off = out.off + coloff; l.out_ld = out.ld;
         l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H);
         l.gout_off = out.off + coloff; l.gzx_off = zx.off;
+        l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
+        if (H > 64) op.fwd.push_back(Step{K_LSTM_T, (int)lstms.size(), 1, 0, H});
         op.fwd.push_back(Step{K_LSTM_F, (int)lstms.size(), 1, B, H});
         op.bwd.push_back(Step{K_LSTM_B, (int)lstms.size(), 1, B, H});
         lstms.push_back(l);
@@ -417,67 +422,63 @@ void mst_plan::build() {
     newT(1, z.NI, "used_instruments"); newT(1, 1, "bpm_target");
     t_losses = newT(1, 64, "losses"); t_saved = newT(1, MST_LOSS_SAVED, "loss_saved"); t_gl = newT(1, 64, "grad_losses");
     loss_scratch = tmp(mst_loss_scratch_floats());
-    auto segI = [&](const T& t) { SegIn s = seg(t, 1, 0, 0, 0, false); return s; };      // per-channel input row
-    auto seg0 = [&](const T& t, bool grad) { return seg(t, 0, 0, 0, 0, grad); };          // global (broadcast) row
-    auto rows1 = [&](int n) { return std::vector<int>{n, 1, 1, 1}; };
-    (void)rows1;
+    auto seg0 = [&](const T& t) { return seg(t, 0, 0, 0, 0, true); };      // broadcast over every row
+    auto rowsT = [&](const T& t, int rows, int cols, int ld) { return T{t.off, rows, cols, ld}; };
+    (void)rowsT;
 
     // ================================================================= stage 1: extract_style
     stage_begin[0] = act_top;
     std::string m = "pitched_channels_encoder";
-    const int rsC[4] = {C, 1, 1, 1}, rsP[4] = {P_, 1, 1, 1}, rsR[4] = {R, 1, 1, 1}, rsQ[4] = {Q_, 1, 1, 1};
-    T pce_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PCE_IL, ACT_LEAKY);
+    T pce_il = linear(E, instr, false, m + ".instruments_linear", z.PCE_IL, ACT_LEAKY);
     T x1 = conv(E);
     const int rsCQ[4] = {C, R * Tn, 1, 1};
-    T pa = linear(E, rsCQ, {seg(x1, R * Tn, 1, 0, 0), seg(pce_il, 1, 0, 0, 0)}, m + ".linear.weight", m + ".linear.bias", z.H, ACT_LEAKY);
+    T pcat = gather(E, rsCQ, {seg(x1, R * Tn, 1, 0, 0), seg(pce_il, 1, 0, 0, 0)});
+    T pa = linear(E, pcat, true, m + ".linear", z.H, ACT_LEAKY);
     T pbeats = newT(P_, z.H, "pitched_beats");
-    lstm(E, rsP, {seg(pa, 1, 0, 0, 0)}, C * R, Tn, z.H, 0, m + ".beats_lstm.module", pbeats, 0);
+    lstm(E, pa, C * R, Tn, z.H, 0, m + ".beats_lstm.module", pbeats, 0);
     T plast = newT(R, z.H);
     combine(E, pbeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, (int64_t)R * Tn * z.H, C, plast);
     T pbars = newT(R, 2 * z.HB, "pitched_bars");
-    lstm(E, rsR, {seg(plast, 1, 0, 0, 0)}, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0);
-    lstm(E, rsR, {seg(plast, 1, 0, 0, 0)}, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB);
+    lstm(E, plast, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0);
+    lstm(E, plast, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB);
 
     m = "pitched_rhythm_encoder";
-    T pre_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PRE_IL, ACT_LEAKY);
-    T pre_ml = linear(E, RS1, {seg0(mode, false)}, m + ".mode_linear.weight", m + ".mode_linear.bias", z.PRE_ML, ACT_LEAKY);
-    T pre_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.PRE_BPL, ACT_LEAKY);
-    T pre_bl = linear(E, rsP, {seg(pbeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.PRE_BL, ACT_LEAKY);
-    T pre_br = linear(E, rsR, {seg(pbars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.PRE_BRL, ACT_LEAKY);
-    const int rsPF[4] = {P_ * NF, 1, 1, 1};
-    T pre_cl = linear(E, rsPF, {segx(SP_EXT0, NPN * NPF, NPN * NPF, 1, 0, 0, 0)}, m + ".channels_linear.weight",
+    T pre_il = linear(E, instr, false, m + ".instruments_linear", z.PRE_IL, ACT_LEAKY);
+    T pre_ml = linear(E, mode, false, m + ".mode_linear", z.PRE_ML, ACT_LEAKY);
+    T pre_bp = linear(E, bpm, false, m + ".bpm_linear", z.PRE_BPL, ACT_LEAKY);
+    T pre_bl = linear(E, pbeats, true, m + ".beats_linear", z.PRE_BL, ACT_LEAKY);
+    T pre_br = linear(E, pbars, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
+    T pre_cl = linear(E, SP_EXT0, 0, NPN * NPF, P_ * NF, NPN * NPF, false, m + ".channels_linear.weight",
                       m + ".channels_linear.bias", z.PRE_CL, ACT_LEAKY);
     const int rsCRTF[4] = {C, R, Tn, NF};
-    T prh_c = linear(E, rsCRTF,
+    T prcat = gather(E, rsCRTF,
                      {seg(pre_bl, R * Tn, Tn, 1, 0), seg(pre_br, 0, 1, 0, 0), seg(pre_cl, R * Tn * NF, Tn * NF, NF, 1),
-                      seg(pre_il, 1, 0, 0, 0), seg0(pre_ml, true), seg0(pre_bp, true)},
-                     m + ".linear.weight", m + ".linear.bias", z.RH, ACT_LEAKY);
+                      seg(pre_il, 1, 0, 0, 0), seg0(pre_ml), seg0(pre_bp)});
+    T prh_c = linear(E, prcat, true, m + ".linear", z.RH, ACT_LEAKY);
     T prh = newT(Q_ * NF, z.RH, "pitched_rhythm");
     combine(E, prh_c.off, Q_ * NF, z.RH, z.RH, (int64_t)Q_ * NF * z.RH, C, prh);
 
     T bars = pbars, rhythm = prh;
     if (U) {
         m = "unpitched_channels_encoder";
-        T ua = linear(E, rsQ, {segx(SP_EXT1, NF * NUN * NUF, NF * NUN * NUF, 1, 0, 0, 0)}, m + ".linear.weight",
-                      m + ".linear.bias", z.H, ACT_LEAKY, nullptr, NUN, NUF);
+        T ua = linear(E, SP_EXT1, 0, NF * NUN * NUF, Q_, NF * NUN * NUF, false, m + ".linear.weight", m + ".linear.bias",
+                      z.H, ACT_LEAKY, nullptr, NUN, NUF);
         T ubeats = newT(Q_, z.H, "unpitched_beats");
-        lstm(E, rsQ, {seg(ua, 1, 0, 0, 0)}, R, Tn, z.H, 0, m + ".beats_lstm.module", ubeats, 0);
+        lstm(E, ua, R, Tn, z.H, 0, m + ".beats_lstm.module", ubeats, 0);
         T ulast = newT(R, z.H);
         combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
         T ubars = newT(R, 2 * z.HB, "unpitched_bars");
-        lstm(E, rsR, {seg(ulast, 1, 0, 0, 0)}, 1, R, z.HB, 0, m + ".bars_lstm", ubars, 0);
-        lstm(E, rsR, {seg(ulast, 1, 0, 0, 0)}, 1, R, z.HB, 1, m + ".bars_lstm", ubars, z.HB);
+        lstm(E, ulast, 1, R, z.HB, 0, m + ".bars_lstm", ubars, 0);
+        lstm(E, ulast, 1, R, z.HB, 1, m + ".bars_lstm", ubars, z.HB);
         m = "unpitched_rhythm_encoder";
-        T ure_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.PRE_BPL, ACT_LEAKY);
-        T ure_bl = linear(E, rsQ, {seg(ubeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.PRE_BL, ACT_LEAKY);
-        T ure_br = linear(E, rsR, {seg(ubars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.PRE_BRL, ACT_LEAKY);
-        const int rsQF[4] = {Q_ * NF, 1, 1, 1};
-        T ure_cl = linear(E, rsQF, {segx(SP_EXT1, NUN * NUF, NUN * NUF, 1, 0, 0, 0)}, m + ".channels_linear.weight",
+        T ure_bp = linear(E, bpm, false, m + ".bpm_linear", z.PRE_BPL, ACT_LEAKY);
+        T ure_bl = linear(E, ubeats, true, m + ".beats_linear", z.PRE_BL, ACT_LEAKY);
+        T ure_br = linear(E, ubars, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
+        T ure_cl = linear(E, SP_EXT1, 0, NUN * NUF, Q_ * NF, NUN * NUF, false, m + ".channels_linear.weight",
                           m + ".channels_linear.bias", z.URE_CL, ACT_LEAKY);
         const int rs1RTF[4] = {1, R, Tn, NF};
-        T urh_c = linear(E, rs1RTF,
-                         {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp, true)},
-                         m + ".linear.weight", m + ".linear.bias", z.RH, ACT_LEAKY);
+        T urcat = gather(E, rs1RTF, {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp)});
+        T urh_c = linear(E, urcat, true, m + ".linear", z.RH, ACT_LEAKY);
         T urh = newT(Q_ * NF, z.RH, "unpitched_rhythm");
         combine(E, urh_c.off, Q_ * NF, z.RH, z.RH, 0, 1, urh);
         // combine(pitched, unpitched) stacks the pair on a new leading axis (style/model.py:766-767)
@@ -490,25 +491,26 @@ void mst_plan::build() {
     }
 
     m = "style_encoder";
-    T se_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.SE_IL, ACT_LEAKY);
-    T se_ml = linear(E, RS1, {seg0(mode, false)}, m + ".mode_linear.weight", m + ".mode_linear.bias", z.SE_ML, ACT_LEAKY);
-    T se_bp = linear(E, RS1, {seg0(bpm, false)}, m + ".bpm_linear.weight", m + ".bpm_linear.bias", z.SE_BL, ACT_LEAKY);
+    T se_il = linear(E, instr, false, m + ".instruments_linear", z.SE_IL, ACT_LEAKY);
+    T se_ml = linear(E, mode, false, m + ".mode_linear", z.SE_ML, ACT_LEAKY);
+    T se_bp = linear(E, bpm, false, m + ".bpm_linear", z.SE_BL, ACT_LEAKY);
     T sel = newT(R, z.SE_L);
-    lstm(E, rsR, {seg(bars, 1, 0, 0, 0)}, 1, R, z.SE_L, 0, m + ".bars_lstm", sel, 0);
+    lstm(E, bars, 1, R, z.SE_L, 0, m + ".bars_lstm", sel, 0);
     T sel_last{sel.off + (int64_t)(R - 1) * z.SE_L, 1, z.SE_L, z.SE_L};
-    T se_lin = linear(E, rsC, {seg0(sel_last, true), seg(se_il, 1, 0, 0, 0), seg0(se_ml, true), seg0(se_bp, true)},
-                      m + ".linear.weight", m + ".linear.bias", z.STYLE, ACT_LEAKY);
+    const int rsC[4] = {C, 1, 1, 1};
+    T secat = gather(E, rsC, {seg0(sel_last), seg(se_il, 1, 0, 0, 0), seg0(se_ml), seg0(se_bp)});
+    T se_lin = linear(E, secat, true, m + ".linear", z.STYLE, ACT_LEAKY);
     T style = newT(1, z.STYLE, "style");
     combine(E, se_lin.off, 1, z.STYLE, z.STYLE, z.STYLE, C, style);
 
     m = "melody_encoder";
-    T me_il = linear(E, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.ME_IL, ACT_LEAKY);
-    T me_bl = linear(E, rsP, {seg(pbeats, 1, 0, 0, 0)}, m + ".beats_linear.weight", m + ".beats_linear.bias", z.ME_BL, ACT_LEAKY);
-    T me_br = linear(E, rsR, {seg(pbars, 1, 0, 0, 0)}, m + ".bars_linear.weight", m + ".bars_linear.bias", z.ME_BRL, ACT_LEAKY);
+    T me_il = linear(E, instr, false, m + ".instruments_linear", z.ME_IL, ACT_LEAKY);
+    T me_bl = linear(E, pbeats, true, m + ".beats_linear", z.ME_BL, ACT_LEAKY);
+    T me_br = linear(E, pbars, true, m + ".bars_linear", z.ME_BRL, ACT_LEAKY);
     const int rsCRT[4] = {C, R, Tn, 1};
-    std::vector<SegIn> ysegs = {seg(me_bl, R * Tn, Tn, 1, 0), seg(me_br, 0, 1, 0, 0), seg(me_il, 1, 0, 0, 0)};
-    T me_oct = linear(E, rsCRT, ysegs, m + ".octave_linear.weight", m + ".octave_linear.bias", z.MEL * NOCT, ACT_LEAKY);
-    T me_deg = linear(E, rsCRT, ysegs, m + ".scale_degree_linear.weight", m + ".scale_degree_linear.bias", z.MEL * NDEG, ACT_LEAKY);
+    T ycat = gather(E, rsCRT, {seg(me_bl, R * Tn, Tn, 1, 0), seg(me_br, 0, 1, 0, 0), seg(me_il, 1, 0, 0, 0)});
+    T me_oct = linear(E, ycat, true, m + ".octave_linear", z.MEL * NOCT, ACT_LEAKY);
+    T me_deg = linear(E, ycat, true, m + ".scale_degree_linear", z.MEL * NDEG, ACT_LEAKY);
     T mel_c = newT(P_ * NF * NPN, z.MEL);
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
@@ -534,36 +536,34 @@ void mst_plan::build() {
     m = "song_info_model";
     T rhy_rows{rhythm.off, Q_, NF * z.RH, NF * z.RH};                    // squash_dims(rhythm, -2)
     T sbl = newT(Q_, z.SIM_BL);
-    lstm(IN, rsQ, {seg(rhy_rows, 1, 0, 0, 0)}, R, Tn, z.SIM_BL, 0, m + ".beats_lstm.module", sbl, 0);
+    lstm(IN, rhy_rows, R, Tn, z.SIM_BL, 0, m + ".beats_lstm.module", sbl, 0);
     T slast{sbl.off + (int64_t)(Tn - 1) * z.SIM_BL, R, z.SIM_BL, Tn * z.SIM_BL};
     T sbr = newT(R, z.NRF);
-    lstm(IN, rsR, {seg(slast, 1, 0, 0, 0)}, 1, R, z.NRF, 0, m + ".bars_lstm", sbr, 0);
+    lstm(IN, slast, 1, R, z.NRF, 0, m + ".bars_lstm", sbr, 0);
     T feats{sbr.off + (int64_t)(R - 1) * z.NRF, 1, z.NRF, z.NRF};
     struct Head { const char* nm; int sw, rw, n, act; const char* out; };
     const Head heads[3] = {{"instruments", z.SIM_SI, z.SIM_RI, z.NI, ACT_NONE, "instruments_pred"},
                            {"mode", z.SIM_SM, z.SIM_RM, 2, ACT_NONE, "mode_pred"},
                            {"bpm", z.SIM_SB, z.SIM_RB, 1, ACT_BPM, "bpm_pred"}};
     for (const Head& h : heads) {
-        const std::string a = m + ".style_" + h.nm + "_linear", b2 = m + ".rhythm_" + h.nm + "_linear", c = m + "." + h.nm + "_linear";
-        T hs = linear(IN, RS1, {seg0(style, true)}, a + ".weight", a + ".bias", h.sw, ACT_LEAKY);
-        T hr = linear(IN, RS1, {seg0(feats, true)}, b2 + ".weight", b2 + ".bias", h.rw, ACT_LEAKY);
-        linear(IN, RS1, {seg0(hs, true), seg0(hr, true)}, c + ".weight", c + ".bias", h.n, h.act, nullptr, 0, 0, h.out);
+        T hs = linear(IN, style, true, m + ".style_" + h.nm + "_linear", h.sw, ACT_LEAKY);
+        T hr = linear(IN, feats, true, m + ".rhythm_" + h.nm + "_linear", h.rw, ACT_LEAKY);
+        T hcat = gather(IN, RS1, {seg0(hs), seg0(hr)});
+        linear(IN, hcat, true, m + "." + h.nm + "_linear", h.n, h.act, h.out);
     }
     stage_end[1] = act_top;
 
     // ================================================================= stage 3: apply_style
     stage_begin[2] = act_top;
     m = "pitched_style_applier";
-    const int rsQF1[4] = {Q_ * NF, 1, 1, 1};
-    T psa_sl = linear(AP, RS1, {seg0(style, true)}, m + ".style_linear.weight", m + ".style_linear.bias", z.PSA_SL, ACT_LEAKY);
-    T psa_rl = linear(AP, rsQF1, {seg(rhythm, 1, 0, 0, 0)}, m + ".rhythm_linear.weight", m + ".rhythm_linear.bias", z.PSA_RL, ACT_LEAKY);
-    T psa_il = linear(AP, rsC, {segI(instr)}, m + ".instruments_linear.weight", m + ".instruments_linear.bias", z.PSA_IL, ACT_LEAKY);
+    T psa_sl = linear(AP, style, true, m + ".style_linear", z.PSA_SL, ACT_LEAKY);
+    T psa_rl = linear(AP, rhythm, true, m + ".rhythm_linear", z.PSA_RL, ACT_LEAKY);
+    T psa_il = linear(AP, instr, false, m + ".instruments_linear", z.PSA_IL, ACT_LEAKY);
     const int rsCQF[4] = {C, Q_ * NF, 1, 1};
-    std::vector<SegIn> asegs = {seg0(psa_sl, true), seg(psa_rl, 0, 1, 0, 0), seg(psa_il, 1, 0, 0, 0)};
-    T lo = linear(AP, rsCQF, asegs, m + ".octave_linear.weight", m + ".octave_linear.bias", NPF * 6 * NOCT, ACT_LEAKY);
-    T ld_ = linear(AP, rsCQF, asegs, m + ".scale_degree_linear.weight", m + ".scale_degree_linear.bias", NPF * 6 * NDEG, ACT_LEAKY);
-    const int rsQFN[4] = {Q_ * NF * NPN, 1, 1, 1};
-    T ml = linear(AP, rsQFN, {seg(melody, 1, 0, 0, 0)}, m + ".melody_linear.weight", m + ".melody_linear.bias", z.PSA_ML, ACT_LEAKY);
+    T acat = gather(AP, rsCQF, {seg0(psa_sl), seg(psa_rl, 0, 1, 0, 0), seg(psa_il, 1, 0, 0, 0)});
+    T lo = linear(AP, acat, true, m + ".octave_linear", NPF * 6 * NOCT, ACT_LEAKY);
+    T ld_ = linear(AP, acat, true, m + ".scale_degree_linear", NPF * 6 * NDEG, ACT_LEAKY);
+    T ml = linear(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
@@ -581,16 +581,14 @@ void mst_plan::build() {
     }
     if (U) {
         m = "unpitched_style_applier";
-        T usa_sl = linear(AP, RS1, {seg0(style, true)}, m + ".style_linear.weight", m + ".style_linear.bias", NF * z.USA_SL, ACT_LEAKY);
-        T usa_rl = linear(AP, rsQF1, {seg(rhythm, 1, 0, 0, 0)}, m + ".rhythm_linear.weight", m + ".rhythm_linear.bias", z.USA_RL, ACT_LEAKY);
+        T usa_sl = linear(AP, style, true, m + ".style_linear", NF * z.USA_SL, ACT_LEAKY);
+        T usa_rl = linear(AP, rhythm, true, m + ".rhythm_linear", z.USA_RL, ACT_LEAKY);
         T sl_view{usa_sl.off, NF, z.USA_SL, z.USA_SL};                   // x.view(1, 1, 1, n_beat_fractions, -1)
         const int rsQ_F[4] = {Q_, NF, 1, 1};
-        T v = linear(AP, rsQ_F, {seg(sl_view, 0, 1, 0, 0), seg(usa_rl, NF, 1, 0, 0)}, m + ".notes_linear.weight",
-                     m + ".notes_linear.bias", NUN * NUF * 4, ACT_LEAKY);
+        T ucat = gather(AP, rsQ_F, {seg(sl_view, 0, 1, 0, 0), seg(usa_rl, NF, 1, 0, 0)});
+        T v = linear(AP, ucat, true, m + ".notes_linear", NUN * NUF * 4, ACT_LEAKY);
         T v_rows{v.off, Q_ * NF * NUN, NUF * 4, NUF * 4};                  // x.view(..., n_unpitched_notes, -1)
-        const int rsQFU[4] = {Q_ * NF * NUN, 1, 1, 1};
-        linear(AP, rsQFU, {seg(v_rows, 1, 0, 0, 0)}, m + ".linear.weight", m + ".linear.bias", NUF, ACT_SIGOUT, nullptr, 0, 0,
-               "unpitched_pred");
+        linear(AP, v_rows, true, m + ".linear", NUF, ACT_SIGOUT, "unpitched_pred");
     }
     stage_end[2] = act_top;
     if (!notes_widths_supported(z.MEL, z.ME_CW, z.PSA_ML)) err = MST_ERR_UNSUPPORTED;
@@ -608,11 +606,13 @@ static int up(const std::vector<D>& v, D** dev) {
 
 int mst_plan::upload() {
     int e = 0;
-    e |= up(gemms, &d_gemms); e |= up(segreds, &d_segreds); e |= up(lstms, &d_lstms);
+    e |= up(gemms, &d_gemms); e |= up(gathers, &d_gathers); e |= up(segreds, &d_segreds); e |= up(lstms, &d_lstms);
     e |= up(combines, &d_combines); e |= up(notes, &d_notes);
     for (int s = 0; s < 3; ++s) {
         e |= up(slabs[s], &d_slabs[s]);
-        for (auto& x : slabs[s]) if (x.count > slab_max[s]) slab_max[s] = x.count;
+        for (size_t i = 0; i < slabs[s].size(); ++i)
+            for (int st = 0; st < slabs[s][i].count; st += 1024) slab_blocks[s].push_back(SlabBlock{(int)i, st});
+        e |= up(slab_blocks[s], &d_slab_blocks[s]);
     }
     return e ? MST_ERR_ALLOC : MST_OK;
 }
@@ -633,8 +633,8 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
-    hipFree(p->d_gemms); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
-    for (int s = 0; s < 3; ++s) hipFree(p->d_slabs[s]);
+    hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
+    for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
     delete p;
 }
 
@@ -655,7 +655,7 @@ extern "C" int32_t mst_plan_launch_count(const mst_plan* p, int32_t mask, int32_
     int n = 0;
     for (auto& op : p->ops) {
         if (!(op.stage & mask)) continue;
-        for (auto& s : (backward ? op.bwd : op.fwd)) n += (s.kind == K_COMB_F || s.kind == K_COMB_B) ? 2 : 1;
+        for (auto& s : (backward ? op.bwd : op.fwd)) n += (s.kind == K_COMB_F || s.kind == K_COMB_B || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
     }
     if (backward) for (int s = 0; s < 3; ++s) if ((mask >> s) & 1) n += 1;
     return n;
@@ -672,8 +672,10 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, s.b, b, st);
-    case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, b, st);
+    case K_GEMM: return launch_gemm(gemm_variant(p->gemms[s.first]), p->d_gemms + s.first, s.count, s.a, s.b, b, st);
+    case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
+    case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
+    case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
     case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, p->combines[s.first], b, st);
@@ -727,7 +729,7 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     }
     for (int s = 2; s >= 0; --s) {
         if (!((mask >> s) & 1)) continue;
-        if (launch_slab_reduce(p->d_slabs[s], (int)p->slabs[s].size(), p->slab_max[s], b, (hipStream_t)stream))
+        if (launch_slab_reduce(p->d_slabs[s], p->d_slab_blocks[s], (int)p->slab_blocks[s].size(), b, (hipStream_t)stream))
             return MST_ERR_LAUNCH;
     }
     return MST_OK;
@@ -784,6 +786,9 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
             b += 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N);
         }
         break;
+    case K_GATHER:
+        for (int i = 0; i < s.count; ++i) { const GatherDesc& g = p->gathers[s.first + i]; b += 8.0 * g.rows * g.K; }
+        break;
     case K_SEGRED:
         for (int i = 0; i < s.count; ++i) {
             const SegRedDesc& r = p->segreds[s.first + i];
@@ -831,6 +836,26 @@ extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t 
     int n = 0;
     for (auto& op : p->ops) if (op.stage & mask) n += (int)(backward ? op.bwd.size() : op.fwd.size());
     return n;
+}
+
+// shape of step i of a pass: GEMM {M,N,K,ksplit} of its first descriptor (+count), LSTM {B,S,H,count},
+// segment-reduce {nidx max, width, rows, count}
+extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 5 per step */) {
+    if (!p || !info) return MST_ERR_ARG;
+    std::vector<const Step*> steps;
+    if (!backward) { for (auto& op : p->ops) if (op.stage & mask) for (auto& s : op.fwd) steps.push_back(&s); }
+    else { for (size_t i = p->ops.size(); i-- > 0;) if (p->ops[i].stage & mask) for (auto& s : p->ops[i].bwd) steps.push_back(&s); }
+    int idx = 0;
+    for (const Step* s : steps) {
+        int32_t* o = info + 5 * idx++;
+        o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count;
+        if (s->kind == K_GEMM) { const GemmDesc& g = p->gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
+        else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
+        else if (s->kind == K_GATHER) { const GatherDesc& g = p->gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
+        else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
+        else if (s->kind == K_COMB_F || s->kind == K_COMB_B) { const CombineDesc& c = p->combines[s->first]; o[0] = c.Cn; o[1] = c.rows; o[2] = c.cols; o[3] = c.nblk; }
+    }
+    return idx;
 }
 
 extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t backward, const float* params, float* gparams,

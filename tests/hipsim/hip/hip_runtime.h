@@ -35,6 +35,8 @@ extern "C" void __sanitizer_finish_switch_fiber(void*, const void**, size_t*);
 #define __launch_bounds__(...)
 #define __shared__ static
 #define HIPSIM 1
+#define MST_GLOBAL_AS
+#define MST_LDS_BARRIER() __syncthreads()
 
 struct dim3 {
     unsigned x, y, z;

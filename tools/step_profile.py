@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer tool: per-launch-step timing table of one training iteration on the bench clip
+(HIP events through mst_plan_time_steps). Usage on the GPU box: python tools/step_profile.py [C R T]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'music-style-transfer_amd')]
+import numpy as np
+import torch
+
+from bench import CLIP, WIDTHS, KIND_NAMES, init_params
+from oracle.synth import synth_clip
+from style import _native as nat
+
+shape = dict(CLIP)
+if len(sys.argv) >= 4:
+    shape = dict(C=int(sys.argv[1]), R=int(sys.argv[2]), T=int(sys.argv[3]))
+dev = torch.device('cuda:0')
+native = nat.get()
+native.lib.mst_plan_step_info.restype = C.c_int32
+dims = nat.Dims(**shape, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+flat, table = init_params(native, dims)
+clip = synth_clip(0, shape['C'], shape['R'], shape['T'], True)
+plan = native.plan(dims, dev)
+plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'], used=clip['used_instruments'], bpm_target=120.)
+params = flat.to(dev); g = torch.zeros_like(params)
+xp, xu = clip['pitched'].to(dev), clip['unpitched'].to(dev)
+plan.train_iteration(params, g, xp, xu)
+torch.cuda.synchronize()
+tot = 0
+for bwd in (False, True):
+    steps = plan.time_steps(7, bwd, params, g, xp, xu, reps=20)
+    info = np.zeros(5 * len(steps), np.int32)
+    native.lib.mst_plan_step_info(C.c_void_p(plan.handle), 7, int(bwd), C.c_void_p(info.ctypes.data))
+    info = info.reshape(-1, 5)
+    print('==== backward' if bwd else '==== forward')
+    for i, ((kind, ms, fl, by), inf) in enumerate(zip(steps, info)):
+        tot += ms
+        print(f'{i:3d} {KIND_NAMES[kind]:22s} {ms*1e3:8.1f} us  {fl/1e6:9.2f} MFLOP {by/1e6:8.2f} MB  info={inf.tolist()}')
+print('sum of steps: %.3f ms' % tot)
