@@ -8,9 +8,10 @@
 // the source tensors — and bias/activation (or the activation derivative on the backward
 // side) are fused into the tile load / epilogue.
 //
-// Tiling: 64x64x32 per 256-thread workgroup (4 waves of 64), 4x4 register micro-tile per
-// lane, LDS tiles stored k-major with a +4 pad so both the float4 fragment reads and the
-// transposed tile writes are (at worst 2-way) bank-conflict free.  blockIdx.y selects the
+// Tiling: 32x32 outputs x 128-deep k-tile per 256-thread workgroup; the four waves split the
+// k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
+// float4 fragment reads).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
+// tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
 // descriptor, so independent small GEMMs share one launch; blockIdx.z is the split of the
 // reduction dimension for weight gradients (deterministic slabs, reduced later in order).
 #include "mst_common.h"
@@ -37,50 +38,32 @@ __device__ __forceinline__ float act_bwd(int act, float y, int col) {
 // every LDS read of the FMA loop).  Loading is two-phase: compute every address of the next
 // k-tile, issue all loads unconditionally (padding / bias-ones columns read a constant from
 // memory instead of branching) so they fly under the current tile's FMAs, consume one tile later.
-__device__ const float k_const[2] = {0.f, 1.f};
 typedef const MST_GLOBAL_AS float* gcptr;
 
-struct Ld { gcptr p; gcptr p2; int col; };
-
+// Element offset of operand(i, j) — branch-free; `ok` is cleared for im2col padding taps.
+// (i, j) = (m, k) for the A operand and (k, n) for the B operand.
 template <int KIND>
-__device__ __forceinline__ Ld addr_of(const Operand& o, gcptr base, gcptr base2, int i, int j, bool valid) {
-    Ld r; r.p = (gcptr)&k_const[0]; r.p2 = (gcptr)&k_const[1]; r.col = 0;
-    if (!valid) return r;
+__device__ __forceinline__ int off_of(const Operand& o, int i, int j, bool& ok) {
     if constexpr (KIND == OPK_DENSE) {
-        r.p = (j == o.ones_at) ? (gcptr)&k_const[1] : base + (unsigned)(i * (int)o.si + j * (int)o.sj);
-    } else if constexpr (KIND == OPK_ACTGRAD) {
-        const int row = o.transposed ? j : i;
-        r.col = o.transposed ? i : j;
-        const unsigned idx = (unsigned)(row * o.ld + r.col);
-        r.p = base + idx;
-        r.p2 = base2 + idx;
-    } else if constexpr (KIND == OPK_IM2COL) {      // i = (p, octave), j = (fraction, tap, feature)
-        if (j == o.ones_at) { r.p = (gcptr)&k_const[1]; return r; }
+        return i * (int)o.si + j * (int)o.sj;
+    } else if constexpr (KIND == OPK_ACTGRAD) {      // value(row, col): transposed => i is the column
+        return o.transposed ? j * o.ld + i : i * o.ld + j;
+    } else if constexpr (KIND == OPK_IM2COL) {       // i = (p, octave), j = (fraction, tap, feature)
         const int p = i >> 3, oc = i & 7;
         const int f = j / (CONV_K * NPF), rem = j - f * (CONV_K * NPF);
         const int e = (NDEG * oc - CONV_PAD) * NPF + rem;
-        if (e >= 0 && e < NPN * NPF) r.p = base + (unsigned)(p * (NF * NPN * NPF) + f * (NPN * NPF) + e);
-    } else if constexpr (KIND == OPK_PERMW) {       // i = (a, b, c) in activation memory order, j = out feature
+        ok = ok & (e >= 0) & (e < NPN * NPF);
+        return p * (NF * NPN * NPF) + f * (NPN * NPF) + e;
+    } else if constexpr (KIND == OPK_PERMW) {        // i = (a, b, c) in activation memory order, j = out feature
         // conv: (fraction, tap, feature) reads W[oc, fraction*5+feature, tap]  (pb=14, pc=5)
         // unpitched linear: (fraction, note, feature) reads W[j, fraction*94 + feature*47 + note]
         const int bc = o.pb * o.pc;
         const int a = i / bc, rem = i - a * bc;
         const int bb = rem / o.pc, c = rem - bb * o.pc;
-        r.p = base + (unsigned)(j * o.ld + a * bc + c * o.pb + bb);
-    } else if constexpr (KIND == OPK_CONVGRAD) {    // i = out channel, j = (p, octave)
-        const int p = j >> 3, oc = j & 7;
-        const unsigned idx = (unsigned)(p * (o.oc * NOCT) + i * NOCT + oc);
-        r.p = base + idx;
-        r.p2 = base2 + idx;
+        return j * o.ld + a * bc + c * o.pb + bb;
+    } else {                                          // OPK_CONVGRAD: i = out channel, j = (p, octave)
+        return (j >> 3) * (o.oc * NOCT) + i * NOCT + (j & 7);
     }
-    return r;
-}
-
-template <int KIND>
-__device__ __forceinline__ float finish(const Operand& o, float v, float y, int col) {
-    if constexpr (KIND == OPK_ACTGRAD) return o.act == ACT_NONE ? v : v * act_bwd(o.act, y, col);
-    else if constexpr (KIND == OPK_CONVGRAD) return v * act_bwd(ACT_LEAKY, y, 0);
-    else return v;
 }
 
 template <int OK>
@@ -111,14 +94,20 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
     }
 }
 
-template <int AK, int BKIND, int OK>
+template <int AK, int BKIND, int OK, int AKF, int BKF>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
+    // 32x32 output tile per workgroup, 128-deep k-tile: wave w owns k rows [32w, 32w+32) of the
+    // tile (in-block split-K), so the dependent k chain is K/128 steps and small problems still
+    // spread over many workgroups; the four partial tiles are summed through LDS at the end.
+    // AKF/BKF: whether consecutive lanes walk k (1) or the m / n index (0) when loading a tile —
+    // the contiguous direction of that operand in memory.
     __shared__ float As[GEMM_BK][GEMM_BM + 4];
     __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
     const int tid = threadIdx.x;
     const GemmDesc& d = descs[blockIdx.y];          // uniform: read through the scalar cache
-    const int tiles_n = (d.N + GEMM_BN - 1) / GEMM_BN;
-    const int tiles_m = (d.M + GEMM_BM - 1) / GEMM_BM;
+    const int M = d.M, N = d.N;
+    const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
     const int tile = blockIdx.x;
     const int split = blockIdx.z;
     if (tile >= tiles_m * tiles_n || split >= d.ksplit) return;   // block-uniform
@@ -130,35 +119,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
     kchunk = (kchunk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
     const int k0 = split * kchunk;
     const int k1 = min(d.K, k0 + kchunk);
-    const int ty = tid >> 4, tx = tid & 15;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int ty = lane >> 3, tx = lane & 7;
+    const int a_act = (AK == OPK_ACTGRAD) ? d.A.act : ACT_LEAKY;
+    const int a_tr = d.A.transposed;
+    const int b_ones = (BKIND == OPK_DENSE || BKIND == OPK_IM2COL) ? d.B.ones_at : -1;   // bias-gradient column of B
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-    // per-thread tile coordinates: element e = tid + 256*i of a 64 x GEMM_BK tile
-    const bool akf = d.A.kfast != 0, bkf = d.B.kfast != 0;
-    constexpr int NL = GEMM_BM * GEMM_BK / 256;      // tile elements per lane and operand
+    constexpr int NL = GEMM_BM * GEMM_BK / 256;      // tile elements per lane and operand (16)
     float va[NL], ya[NL], vb[NL];
-    int cola[NL];
 
+    // element e = tid + 256*i of the 32 x 128 tile: (row, k) = (e / 128, e % 128) when lanes walk k,
+    // (e % 32, e / 32) when lanes walk the row index
+#define A_ROW(i) (AKF ? (tid >> 7) + 2 * (i) : (tid & 31))
+#define A_KL(i) (AKF ? (tid & 127) : (tid >> 5) + 8 * (i))
+#define B_ROW(i) (BKF ? (tid >> 7) + 2 * (i) : (tid & 31))
+#define B_KL(i) (BKF ? (tid & 127) : (tid >> 5) + 8 * (i))
 #define GEMM_ISSUE(KT)                                                                                     \
     {                                                                                                      \
-        Ld la[NL], lb[NL];                                                                                 \
         _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
-            const int e = tid + i * 256;                                                                   \
-            const int m = tm * GEMM_BM + (akf ? e / GEMM_BK : e % GEMM_BM);                                \
-            const int ka = (KT) + (akf ? e % GEMM_BK : e / GEMM_BM);                                       \
-            la[i] = addr_of<AK>(d.A, baseA, baseA2, m, ka, m < d.M && ka < k1);                            \
-            const int n = tn * GEMM_BN + (bkf ? e / GEMM_BK : e % GEMM_BN);                                \
-            const int kb = (KT) + (bkf ? e % GEMM_BK : e / GEMM_BN);                                       \
-            lb[i] = addr_of<BKIND>(d.B, baseB, baseB, kb, n, n < d.N && kb < k1);                          \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
-            va[i] = *la[i].p; cola[i] = la[i].col;                                                         \
-            if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ya[i] = *la[i].p2; else ya[i] = 1.f;    \
-            vb[i] = *lb[i].p;                                                                              \
+            const int m = tm * GEMM_BM + A_ROW(i), ka = (KT) + A_KL(i);                                    \
+            bool oka = (m < M) & (ka < k1);                                                                \
+            int ia = off_of<AK>(d.A, m, ka, oka);                                                          \
+            ia = oka ? ia : 0;                                                                             \
+            const float x = baseA[(unsigned)ia];                                                           \
+            if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                       \
+                const float y = baseA2[(unsigned)ia];                                                      \
+                const int col = (AK == OPK_ACTGRAD) ? (a_tr ? m : ka) : 0;                                 \
+                ya[i] = act_bwd(a_act, y, col);                                                            \
+            } else ya[i] = 1.f;                                                                            \
+            va[i] = oka ? x : 0.f;                                                                         \
+            const int n = tn * GEMM_BN + B_ROW(i), kb = (KT) + B_KL(i);                                    \
+            bool okb = (n < N) & (kb < k1);                                                                \
+            const bool one = okb & (n == b_ones);                                                          \
+            int ib = off_of<BKIND>(d.B, kb, n, okb);                                                       \
+            ib = (okb & !one) ? ib : 0;                                                                    \
+            const float w = baseB[(unsigned)ib];                                                           \
+            vb[i] = one ? 1.f : (okb ? w : 0.f);                                                           \
         }                                                                                                  \
     }
 
@@ -166,17 +167,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
     for (int kt = k0; kt < k1; kt += GEMM_BK) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int e = tid + i * 256;
-            As[akf ? e % GEMM_BK : e / GEMM_BM][akf ? e / GEMM_BK : e % GEMM_BM] = finish<AK>(d.A, va[i], ya[i], cola[i]);
-            Bs[bkf ? e % GEMM_BK : e / GEMM_BN][bkf ? e / GEMM_BK : e % GEMM_BN] = vb[i];
+            As[A_KL(i)][A_ROW(i)] = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? va[i] * ya[i] : va[i];
+            Bs[B_KL(i)][B_ROW(i)] = vb[i];
         }
         __syncthreads();
         if (kt + GEMM_BK < k1) GEMM_ISSUE(kt + GEMM_BK)      // next tile's loads fly under this tile's FMAs
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK; ++kk) {
+        for (int kk = 0; kk < GEMM_KW; ++kk) {
+            const int k = wv * GEMM_KW + kk;
             float a[4], bb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; bb[i] = Bs[kk][tx * 4 + i]; }
+            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; bb[i] = Bs[k][tx * 4 + i]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -185,17 +186,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
         __syncthreads();
     }
 #undef GEMM_ISSUE
+#undef A_ROW
+#undef A_KL
+#undef B_ROW
+#undef B_KL
+    // sum the four waves' partial tiles (fixed order) and run the epilogue, 4 outputs per lane
+    float* red = &As[0][0];                          // 4 x 32 x 32 floats fit in the A tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wv * (GEMM_BM * GEMM_BN) + (ty * 4 + i) * GEMM_BN + tx * 4 + j] = acc[i][j];
+    __syncthreads();
     float* cbase = b.p[d.out.space] + d.out.off;
     const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tm * GEMM_BM + ty * 4 + i;
-        if (m >= d.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tn * GEMM_BN + tx * 4 + j;
-            if (n < d.N) store_out<OK>(d, cbase, bias, m, n, split, acc[i][j]);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int o = tid + q * 256;
+        const int m = tm * GEMM_BM + o / GEMM_BN, n = tn * GEMM_BN + o % GEMM_BN;
+        const float v = (red[o] + red[GEMM_BM * GEMM_BN + o]) + (red[2 * GEMM_BM * GEMM_BN + o] + red[3 * GEMM_BM * GEMM_BN + o]);
+        if (m < M && n < N) store_out<OK>(d, cbase, bias, m, n, split, v);
     }
 }
 
@@ -215,16 +224,16 @@ int gemm_variant(const GemmDesc& g) {
 int launch_gemm(int variant, const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
     const dim3 grid(max_tiles, count, max_split), block(256);
-#define GEMM_GO(A_, B_, O_) hipLaunchKernelGGL((gemm_kernel<A_, B_, O_>), grid, block, 0, s, dev_descs, b); break;
+#define GEMM_GO(A_, B_, O_, AF_, BF_) hipLaunchKernelGGL((gemm_kernel<A_, B_, O_, AF_, BF_>), grid, block, 0, s, dev_descs, b); break;
     switch (variant) {
-    case GV_LIN_FWD: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_STORE)
-    case GV_LIN_FWD_PERM: GEMM_GO(OPK_DENSE, OPK_PERMW, OUT_STORE)
-    case GV_LIN_DW: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_SLAB)
-    case GV_LIN_DW_PERM: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB)
-    case GV_LIN_DA: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM)
-    case GV_CONV_FWD: GEMM_GO(OPK_IM2COL, OPK_PERMW, OUT_CONV)
-    case GV_CONV_DW: GEMM_GO(OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB)
-    case GV_HH_DW: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_SLAB)
+    case GV_LIN_FWD: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1)
+    case GV_LIN_FWD_PERM: GEMM_GO(OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1)
+    case GV_LIN_DW: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0)
+    case GV_LIN_DW_PERM: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0)
+    case GV_LIN_DA: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0)
+    case GV_CONV_FWD: GEMM_GO(OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1)
+    case GV_CONV_DW: GEMM_GO(OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0)
+    case GV_HH_DW: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0)
     default: return MST_ERR_UNSUPPORTED;
     }
 #undef GEMM_GO

@@ -175,6 +175,7 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, h
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s);
 bool notes_widths_supported(int W, int CW, int ML);
 
-#define GEMM_BM 64
-#define GEMM_BN 64
-#define GEMM_BK 32
+#define GEMM_BM 32
+#define GEMM_BN 32
+#define GEMM_BK 128     // k-tile staged in LDS per step
+#define GEMM_KW 32      // k rows of the tile each of the 4 waves reduces

@@ -217,8 +217,8 @@ struct mst_plan {
     }
     int64_t tmp(int64_t n) { int64_t o = tmp_top; tmp_top += align(n); return o; }
     static int tiles(int M, int N) { return ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN); }
-    // weight-gradient GEMMs reduce over rows: one k-split per 64 rows (2 k-tiles), capped at 256 slabs
-    static int splits_for(int K) { int s = (K + 63) / 64; return s < 1 ? 1 : (s > 256 ? 256 : s); }
+    // weight-gradient GEMMs reduce over rows: one k-split per 256 rows (2 k-tiles), capped at 64 slabs
+    static int splits_for(int K) { int s = (K + 255) / 256; return s < 1 ? 1 : (s > 64 ? 64 : s); }
 
     static SegIn seg(const T& t, int s0, int s1, int s2, int s3, bool grad = true) {
         return SegIn{SP_WS, t.off, t.ld, t.cols, {s0, s1, s2, s3}, grad};
@@ -362,36 +362,60 @@ struct mst_plan {
         return x1;
     }
 
-    // one LSTM direction: input projection (a linear op) + the recurrence op
-    void lstm(int stage, const T& x, int B, int S, int H, int reverse, const std::string& pre, const T& out, int coloff) {
-        const std::string sfx = reverse ? "_reverse" : "";
-        T zx = linear(stage, SP_WS, x.off, x.ld, x.rows, x.cols, true, pre + ".weight_ih_l0" + sfx, pre + ".bias_ih_l0" + sfx,
-                      4 * H, ACT_NONE);
-        if (4 * H > 1024) err = MST_ERR_UNSUPPORTED;
-        const int64_t whh = pt.off(pre + ".weight_hh_l0" + sfx), bhh = pt.off(pre + ".bias_hh_l0" + sfx);
-        const int64_t n = (int64_t)B * S;
+    // LSTM directions that do not depend on each other: their input projections are ordinary linear
+    // ops, the recurrences share ONE launch (blockIdx.y = member), and so do the W_hh-gradient GEMMs.
+    struct LstmSpec { T x; int B, S, H, reverse; std::string pre; T out; int coloff; };
+    void lstm_group(int stage, const std::vector<LstmSpec>& specs) {
+        std::vector<T> zxs;
+        for (auto& sp : specs) {
+            const std::string sfx = sp.reverse ? "_reverse" : "";
+            zxs.push_back(linear(stage, SP_WS, sp.x.off, sp.x.ld, sp.x.rows, sp.x.cols, true, sp.pre + ".weight_ih_l0" + sfx,
+                                 sp.pre + ".bias_ih_l0" + sfx, 4 * sp.H, ACT_NONE));
+        }
         Op op; op.stage = stage;
-        LstmDesc l{}; l.B = B; l.S = S; l.H = H; l.reverse = reverse; l.zx_off = zx.off; l.whh_off = whh; l.bhh_off = bhh;
-        l.out_off = out.off + coloff; l.out_ld = out.ld;
-        l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H);
-        l.gout_off = out.off + coloff; l.gzx_off = zx.off;
-        l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
-        if (H > 64) op.fwd.push_back(Step{K_LSTM_T, (int)lstms.size(), 1, 0, H});
-        op.fwd.push_back(Step{K_LSTM_F, (int)lstms.size(), 1, B, H});
-        op.bwd.push_back(Step{K_LSTM_B, (int)lstms.size(), 1, B, H});
-        lstms.push_back(l);
-        GemmDesc w{}; w.M = 4 * H; w.N = H + 1; w.K = (int)n; w.ksplit = splits_for((int)n);
-        w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = zx.off; w.A.si = 1; w.A.sj = 4 * H; w.A.ones_at = -1; w.A.kfast = 0;
-        w.B.kind = OPK_DENSE; w.B.space = SP_TMP; w.B.off = l.hprev_off; w.B.si = H; w.B.sj = 1; w.B.ones_at = H; w.B.kfast = 0;
-        const int64_t stride = (int64_t)4 * H * H + 4 * H;
-        const int64_t slab = tmp(stride * w.ksplit);
-        w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = H;
-        w.out.bias_space = -1;
-        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
-        gemms.push_back(w);
-        slabs[stage_idx(stage)].push_back(SlabEntry{whh, slab, stride, 4 * H * H, w.ksplit});
-        slabs[stage_idx(stage)].push_back(SlabEntry{bhh, slab + (int64_t)4 * H * H, stride, 4 * H, w.ksplit});
+        const int first = (int)lstms.size();
+        int maxB = 1, maxH = 1, minH = 1 << 30, maxTiles = 1, maxSplit = 1;
+        std::vector<GemmDesc> hh;
+        for (size_t i = 0; i < specs.size(); ++i) {
+            const LstmSpec& sp = specs[i];
+            const int H = sp.H;
+            if (4 * H > 1024) err = MST_ERR_UNSUPPORTED;
+            const std::string sfx = sp.reverse ? "_reverse" : "";
+            const int64_t whh = pt.off(sp.pre + ".weight_hh_l0" + sfx), bhh = pt.off(sp.pre + ".bias_hh_l0" + sfx);
+            const int64_t n = (int64_t)sp.B * sp.S;
+            LstmDesc l{}; l.B = sp.B; l.S = sp.S; l.H = H; l.reverse = sp.reverse; l.zx_off = zxs[i].off; l.whh_off = whh; l.bhh_off = bhh;
+            l.out_off = sp.out.off + sp.coloff; l.out_ld = sp.out.ld;
+            l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H);
+            l.gout_off = sp.out.off + sp.coloff; l.gzx_off = zxs[i].off;
+            l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
+            lstms.push_back(l);
+            if (sp.B > maxB) maxB = sp.B;
+            if (H > maxH) maxH = H;
+            if (H < minH) minH = H;
+            GemmDesc w{}; w.M = 4 * H; w.N = H + 1; w.K = (int)n; w.ksplit = splits_for((int)n);
+            w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = zxs[i].off; w.A.si = 1; w.A.sj = 4 * H; w.A.ones_at = -1; w.A.kfast = 0;
+            w.B.kind = OPK_DENSE; w.B.space = SP_TMP; w.B.off = l.hprev_off; w.B.si = H; w.B.sj = 1; w.B.ones_at = H; w.B.kfast = 0;
+            const int64_t stride = (int64_t)4 * H * H + 4 * H;
+            const int64_t slab = tmp(stride * w.ksplit);
+            w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = H;
+            w.out.bias_space = -1;
+            hh.push_back(w);
+            if (tiles(w.M, w.N) > maxTiles) maxTiles = tiles(w.M, w.N);
+            if (w.ksplit > maxSplit) maxSplit = w.ksplit;
+            slabs[stage_idx(stage)].push_back(SlabEntry{whh, slab, stride, 4 * H * H, w.ksplit});
+            slabs[stage_idx(stage)].push_back(SlabEntry{bhh, slab + (int64_t)4 * H * H, stride, 4 * H, w.ksplit});
+        }
+        if (maxH > 64 && minH <= 64) err = MST_ERR_UNSUPPORTED;       // one register/L2 flavour per launch
+        const int cnt = (int)specs.size();
+        if (maxH > 64) op.fwd.push_back(Step{K_LSTM_T, first, cnt, 0, maxH});
+        op.fwd.push_back(Step{K_LSTM_F, first, cnt, maxB, maxH});
+        op.bwd.push_back(Step{K_LSTM_B, first, cnt, maxB, maxH});
+        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), cnt, maxTiles, maxSplit});
+        for (auto& w : hh) gemms.push_back(w);
         ops.push_back(op);
+    }
+    void lstm(int stage, const T& x, int B, int S, int H, int reverse, const std::string& pre, const T& out, int coloff) {
+        lstm_group(stage, {LstmSpec{x, B, S, H, reverse, pre, out, coloff}});
     }
 
     void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out) {
@@ -434,13 +458,29 @@ void mst_plan::build() {
     const int rsCQ[4] = {C, R * Tn, 1, 1};
     T pcat = gather(E, rsCQ, {seg(x1, R * Tn, 1, 0, 0), seg(pce_il, 1, 0, 0, 0)});
     T pa = linear(E, pcat, true, m + ".linear", z.H, ACT_LEAKY);
-    T pbeats = newT(P_, z.H, "pitched_beats");
-    lstm(E, pa, C * R, Tn, z.H, 0, m + ".beats_lstm.module", pbeats, 0);
-    T plast = newT(R, z.H);
+    const std::string mu = "unpitched_channels_encoder";
+    T pbeats = newT(P_, z.H, "pitched_beats"), ubeats{}, ua{};
+    std::vector<LstmSpec> beat_group = {LstmSpec{pa, C * R, Tn, z.H, 0, m + ".beats_lstm.module", pbeats, 0}};
+    if (U) {
+        ua = linear(E, SP_EXT1, 0, NF * NUN * NUF, Q_, NF * NUN * NUF, false, mu + ".linear.weight", mu + ".linear.bias",
+                    z.H, ACT_LEAKY, nullptr, NUN, NUF);
+        ubeats = newT(Q_, z.H, "unpitched_beats");
+        beat_group.push_back(LstmSpec{ua, R, Tn, z.H, 0, mu + ".beats_lstm.module", ubeats, 0});
+    }
+    lstm_group(E, beat_group);
+    T plast = newT(R, z.H), ulast{};
     combine(E, pbeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, (int64_t)R * Tn * z.H, C, plast);
-    T pbars = newT(R, 2 * z.HB, "pitched_bars");
-    lstm(E, plast, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0);
-    lstm(E, plast, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB);
+    T pbars = newT(R, 2 * z.HB, "pitched_bars"), ubars{};
+    std::vector<LstmSpec> bar_group = {LstmSpec{plast, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0},
+                                       LstmSpec{plast, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB}};
+    if (U) {
+        ulast = newT(R, z.H);
+        combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
+        ubars = newT(R, 2 * z.HB, "unpitched_bars");
+        bar_group.push_back(LstmSpec{ulast, 1, R, z.HB, 0, mu + ".bars_lstm", ubars, 0});
+        bar_group.push_back(LstmSpec{ulast, 1, R, z.HB, 1, mu + ".bars_lstm", ubars, z.HB});
+    }
+    lstm_group(E, bar_group);
 
     m = "pitched_rhythm_encoder";
     T pre_il = linear(E, instr, false, m + ".instruments_linear", z.PRE_IL, ACT_LEAKY);
@@ -460,16 +500,6 @@ void mst_plan::build() {
 
     T bars = pbars, rhythm = prh;
     if (U) {
-        m = "unpitched_channels_encoder";
-        T ua = linear(E, SP_EXT1, 0, NF * NUN * NUF, Q_, NF * NUN * NUF, false, m + ".linear.weight", m + ".linear.bias",
-                      z.H, ACT_LEAKY, nullptr, NUN, NUF);
-        T ubeats = newT(Q_, z.H, "unpitched_beats");
-        lstm(E, ua, R, Tn, z.H, 0, m + ".beats_lstm.module", ubeats, 0);
-        T ulast = newT(R, z.H);
-        combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
-        T ubars = newT(R, 2 * z.HB, "unpitched_bars");
-        lstm(E, ulast, 1, R, z.HB, 0, m + ".bars_lstm", ubars, 0);
-        lstm(E, ulast, 1, R, z.HB, 1, m + ".bars_lstm", ubars, z.HB);
         m = "unpitched_rhythm_encoder";
         T ure_bp = linear(E, bpm, false, m + ".bpm_linear", z.PRE_BPL, ACT_LEAKY);
         T ure_bl = linear(E, ubeats, true, m + ".beats_linear", z.PRE_BL, ACT_LEAKY);
