@@ -95,16 +95,13 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
 }
 
 template <int AK, int BKIND, int OK, int AKF, int BKF>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
+__device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, float (*As)[GEMM_BM + 4], float (*Bs)[GEMM_BN + 4]) {
     // 32x32 output tile per workgroup, 128-deep k-tile: wave w owns k rows [32w, 32w+32) of the
     // tile (in-block split-K), so the dependent k chain is K/128 steps and small problems still
     // spread over many workgroups; the four partial tiles are summed through LDS at the end.
     // AKF/BKF: whether consecutive lanes walk k (1) or the m / n index (0) when loading a tile —
     // the contiguous direction of that operand in memory.
-    __shared__ float As[GEMM_BK][GEMM_BM + 4];
-    __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
     const int tid = threadIdx.x;
-    const GemmDesc& d = descs[blockIdx.y];          // uniform: read through the scalar cache
     const int M = d.M, N = d.N;
     const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
     const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
@@ -208,6 +205,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
     }
 }
 
+// One kernel for every GEMM of the model: blockIdx.y picks the descriptor, the descriptor's
+// (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
+// GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
+// all small Linears of one dependency level — into a single launch.
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
+    __shared__ float As[GEMM_BK][GEMM_BM + 4];
+    __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
+    const GemmDesc& d = descs[blockIdx.y];          // uniform: read through the scalar cache
+    switch (d.variant) {
+    case GV_LIN_FWD: gemm_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, As, Bs); break;
+    case GV_LIN_FWD_PERM: gemm_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, As, Bs); break;
+    case GV_LIN_DW: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, As, Bs); break;
+    case GV_LIN_DW_PERM: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, As, Bs); break;
+    case GV_LIN_DA: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, As, Bs); break;
+    case GV_CONV_FWD: gemm_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, As, Bs); break;
+    case GV_CONV_DW: gemm_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, As, Bs); break;
+    case GV_HH_DW: gemm_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, As, Bs); break;
+    default: break;
+    }
+}
+
 int gemm_variant(const GemmDesc& g) {
     const int a = g.A.kind, bk = g.B.kind, o = g.out.kind;
     if (a == OPK_DENSE && bk == OPK_DENSE && o == OUT_STORE) return GV_LIN_FWD;
@@ -221,22 +239,9 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(int variant, const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
+int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-    const dim3 grid(max_tiles, count, max_split), block(256);
-#define GEMM_GO(A_, B_, O_, AF_, BF_) hipLaunchKernelGGL((gemm_kernel<A_, B_, O_, AF_, BF_>), grid, block, 0, s, dev_descs, b); break;
-    switch (variant) {
-    case GV_LIN_FWD: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1)
-    case GV_LIN_FWD_PERM: GEMM_GO(OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1)
-    case GV_LIN_DW: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0)
-    case GV_LIN_DW_PERM: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0)
-    case GV_LIN_DA: GEMM_GO(OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0)
-    case GV_CONV_FWD: GEMM_GO(OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1)
-    case GV_CONV_DW: GEMM_GO(OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0)
-    case GV_HH_DW: GEMM_GO(OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0)
-    default: return MST_ERR_UNSUPPORTED;
-    }
-#undef GEMM_GO
+    hipLaunchKernelGGL(gemm_kernel, dim3(max_tiles, count, max_split), dim3(256), 0, s, dev_descs, b);
     return (int)hipGetLastError();
 }
 
@@ -351,9 +356,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
         const int i = blk.start + q * 256 + threadIdx.x;
         if (i < e.count) {
             const float* src = b.p[SP_TMP] + e.src + i;
-            float acc = 0.f;
-            for (int s = 0; s < e.splits; ++s) acc += src[(int64_t)s * e.stride];
-            b.p[SP_GPAR][e.dst + i] += acc;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // 4 independent chains keep 4+ loads in flight
+            int sp = 0;
+            for (; sp + 4 <= e.splits; sp += 4) {
+                a0 += src[(int64_t)sp * e.stride];
+                a1 += src[(int64_t)(sp + 1) * e.stride];
+                a2 += src[(int64_t)(sp + 2) * e.stride];
+                a3 += src[(int64_t)(sp + 3) * e.stride];
+            }
+            for (; sp < e.splits; ++sp) a0 += src[(int64_t)sp * e.stride];
+            b.p[SP_GPAR][e.dst + i] += (a0 + a1) + (a2 + a3);
         }
     }
 }

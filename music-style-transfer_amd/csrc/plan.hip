@@ -186,7 +186,8 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
 enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T };
-struct Step { int kind, first, count, a, b; };
+struct Step { int kind, first, count, a, b, stage; };
+struct Acc { int space; int64_t lo, hi; bool w; };
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
 static int stage_idx(int stage) { return stage == MST_STAGE_EXTRACT ? 0 : stage == MST_STAGE_INFO ? 1 : 2; }
@@ -196,6 +197,9 @@ struct mst_plan {
     std::vector<GemmDesc> gemms; std::vector<GatherDesc> gathers; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
     std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<SlabEntry> slabs[3];
     std::vector<Op> ops;
+    // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
+    std::vector<Step> sched[2];
+    std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
@@ -432,6 +436,9 @@ struct mst_plan {
     }
 
     void build();
+    void accesses(const Step& s, std::vector<Acc>& out) const;
+    void schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out);
+    void schedule();
     int upload();
 };
 
@@ -549,7 +556,7 @@ void mst_plan::build() {
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
         n.out_off = mel_c.off; n.g_out_off = mel_c.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
         const int nw = z.ME_CW * NPF + z.ME_CW + z.MEL * (z.MEL + z.ME_CW) + z.MEL;
-        n.nblk = P_ < 256 ? P_ : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        n.nblk = P_ < 128 ? P_ : 128; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = E;
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
@@ -602,7 +609,7 @@ void mst_plan::build() {
         n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
         const int qf = Q_ * NF;
-        n.nblk = qf < 512 ? qf : 512; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        n.nblk = qf < 256 ? qf : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
@@ -625,6 +632,202 @@ void mst_plan::build() {
     if (z.H > 256 || z.SE_L > 256 || z.HB > 256) err = MST_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------ scheduler
+// Every launch step's read / write ranges are derived from its descriptors; a step's level is one
+// more than the deepest earlier step it conflicts with (RAW / WAR / WAW on overlapping ranges of the
+// activation, gradient or scratch arena; parameters and the borrowed note tensors are read-only).
+// All steps of one level, stage and kernel are then merged into one launch (blockIdx.y = member).
+static void acc_add(std::vector<Acc>& v, int space, int64_t lo, int64_t len, bool w) {
+    if (space != SP_WS && space != SP_GRAD && space != SP_TMP) return;
+    if (len <= 0) return;
+    v.push_back(Acc{space, lo, lo + len, w});
+}
+
+static void operand_acc(std::vector<Acc>& v, const Operand& o, int di, int dj, int ones) {
+    switch (o.kind) {
+    case OPK_DENSE: {
+        const int64_t si = o.si < 0 ? -o.si : o.si, sj = o.sj < 0 ? -o.sj : o.sj;
+        const int dj_eff = ones >= 0 ? dj - 1 : dj;
+        acc_add(v, o.space, o.off, (int64_t)(di - 1) * si + (int64_t)(dj_eff > 0 ? dj_eff - 1 : 0) * sj + 1, false);
+        break;
+    }
+    case OPK_ACTGRAD: {
+        const int rows = o.transposed ? dj : di;
+        acc_add(v, o.space, o.off, (int64_t)rows * o.ld, false);
+        acc_add(v, o.space2, o.off2, (int64_t)rows * o.ld, false);
+        break;
+    }
+    case OPK_CONVGRAD: {
+        const int64_t n = (int64_t)(dj / NOCT) * o.oc * NOCT;
+        acc_add(v, o.space, o.off, n, false);
+        acc_add(v, o.space2, o.off2, n, false);
+        break;
+    }
+    default: break;      // IM2COL / PERMW read the borrowed inputs / parameters
+    }
+}
+
+void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
+    for (int i = 0; i < s.count; ++i) {
+        switch (s.kind) {
+        case K_GEMM: {
+            const GemmDesc& g = gemms[s.first + i];
+            operand_acc(v, g.A, g.M, g.K, -1);
+            operand_acc(v, g.B, g.K, g.N, g.B.ones_at);
+            const OutSpec& o = g.out;
+            if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
+            else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
+            else if (o.kind == OUT_CONV) acc_add(v, o.space, o.off, (int64_t)(g.M / NOCT) * o.ldc, true);
+            else acc_add(v, o.space, o.off, o.slab_stride * g.ksplit, true);
+            break;
+        }
+        case K_GATHER: {
+            const GatherDesc& g = gathers[s.first + i];
+            for (int q = 0; q < g.nseg; ++q) {
+                const Seg& sg = g.seg[q];
+                int64_t maxrow = 0;
+                for (int k = 0; k < 4; ++k) maxrow += (int64_t)(g.d[k] - 1) * sg.s[k];
+                acc_add(v, sg.space, sg.off, maxrow * sg.ld + sg.width, false);
+            }
+            acc_add(v, SP_WS, g.out_off, (int64_t)g.rows * g.K, true);
+            break;
+        }
+        case K_SEGRED: {
+            const SegRedDesc& r = segreds[s.first + i];
+            const int64_t rows = (int64_t)r.d[0] * r.d[1] * r.d[2] * r.d[3];
+            acc_add(v, SP_GRAD, r.src_off, rows * r.src_ld, false);
+            acc_add(v, SP_GRAD, r.dst_off, (int64_t)(r.nidx - 1) * r.dst_ld + r.width, true);
+            if (r.nchunk > 1) acc_add(v, SP_TMP, r.part_off, (int64_t)r.nidx * r.nchunk * r.width, true);
+            break;
+        }
+        case K_LSTM_T: {
+            const LstmDesc& l = lstms[s.first + i];
+            if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, true);
+            break;
+        }
+        case K_LSTM_F: {
+            const LstmDesc& l = lstms[s.first + i];
+            const int64_t n = (int64_t)l.B * l.S;
+            acc_add(v, SP_WS, l.zx_off, n * 4 * l.H, false);
+            acc_add(v, SP_WS, l.out_off, (n - 1) * l.out_ld + l.H, true);
+            acc_add(v, SP_TMP, l.gates_off, n * 4 * l.H, true);
+            acc_add(v, SP_TMP, l.c_off, n * l.H, true);
+            acc_add(v, SP_TMP, l.hprev_off, n * l.H, true);
+            if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, false);
+            break;
+        }
+        case K_LSTM_B: {
+            const LstmDesc& l = lstms[s.first + i];
+            const int64_t n = (int64_t)l.B * l.S;
+            acc_add(v, SP_TMP, l.gates_off, n * 4 * l.H, false);
+            acc_add(v, SP_TMP, l.c_off, n * l.H, false);
+            acc_add(v, SP_GRAD, l.gout_off, (n - 1) * l.out_ld + l.H, false);
+            acc_add(v, SP_GRAD, l.gzx_off, n * 4 * l.H, true);
+            break;
+        }
+        case K_COMB_F: case K_COMB_B: {
+            const CombineDesc& c = combines[s.first + i];
+            const int64_t span = (int64_t)(c.Cn - 1) * (c.cs < 0 ? -c.cs : c.cs) + (int64_t)(c.rows - 1) * c.ld + c.cols;
+            const int64_t lo = c.cs < 0 ? c.x_off + (int64_t)(c.Cn - 1) * c.cs : c.x_off;
+            const int64_t n = (int64_t)c.rows * c.cols;
+            acc_add(v, SP_WS, lo, span, false);
+            acc_add(v, SP_TMP, c.part_off, COMBINE_MAXBLK * (COMBINE_MAXC + 1), true);
+            if (s.kind == K_COMB_F) {
+                acc_add(v, SP_WS, c.out_off, n, true);
+                acc_add(v, SP_TMP, c.stats_off, 64, true);
+            } else {
+                acc_add(v, SP_WS, c.out_off, n, false);
+                acc_add(v, SP_TMP, c.stats_off, 64, false);
+                acc_add(v, SP_GRAD, c.gout_off, n, false);
+                acc_add(v, SP_GRAD, lo - c.x_off + c.gx_off, span, true);
+            }
+            break;
+        }
+        case K_ME_F: case K_ME_B: case K_PSA_F: case K_PSA_B: {
+            const NotesDesc& n = notes[s.first + i];
+            const bool me = s.kind == K_ME_F || s.kind == K_ME_B, bwd = s.kind == K_ME_B || s.kind == K_PSA_B;
+            const int64_t pos = (int64_t)n.C * n.Q * NF * NPN;
+            const int64_t rows = me ? (int64_t)n.C * n.Q : (int64_t)n.C * n.Q * NF;
+            const int ow = me ? NOCT * n.W : NOCT * 30, dw = me ? NDEG * n.W : NDEG * 30, outw = me ? n.W : NPF;
+            const int64_t mln = (int64_t)n.Q * NF * NPN * n.ML;
+            acc_add(v, SP_WS, n.oct_off, rows * ow, false);
+            acc_add(v, SP_WS, n.deg_off, rows * dw, false);
+            if (!me) acc_add(v, SP_WS, n.ml_off, mln, false);
+            acc_add(v, SP_WS, n.out_off, pos * outw, !bwd);
+            if (bwd) {
+                acc_add(v, SP_GRAD, n.g_out_off, pos * outw, false);
+                acc_add(v, SP_GRAD, n.g_oct_off, rows * ow, true);
+                acc_add(v, SP_GRAD, n.g_deg_off, rows * dw, true);
+                if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
+                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
+            }
+            break;
+        }
+        }
+    }
+}
+
+static bool conflicts(const std::vector<Acc>& a, const std::vector<Acc>& b) {
+    for (const Acc& x : a)
+        for (const Acc& y : b)
+            if (x.space == y.space && (x.w || y.w) && x.lo < y.hi && y.lo < x.hi) return true;
+    return false;
+}
+
+void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out) {
+    const int n = (int)seq.size();
+    std::vector<std::vector<Acc>> acc(n);
+    std::vector<int> level(n, 0);
+    int maxlevel = 0;
+    for (int i = 0; i < n; ++i) {
+        accesses(seq[i], acc[i]);
+        for (int j = 0; j < i; ++j)
+            if (level[j] >= level[i] && conflicts(acc[i], acc[j])) level[i] = level[j] + 1;
+        if (level[i] > maxlevel) maxlevel = level[i];
+    }
+    std::vector<char> done(n, 0);
+    for (int lv = 0; lv <= maxlevel; ++lv) {
+        for (int i = 0; i < n; ++i) {
+            if (done[i] || level[i] != lv) continue;
+            const Step& s0 = seq[i];
+            const bool mergeable = s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
+                                   s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
+            Step m = s0; m.count = 0;
+            if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
+            else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
+            else if (s0.kind == K_SEGRED) m.first = (int)s_segreds.size();
+            else if (s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B) m.first = (int)s_lstms.size();
+            for (int j = i; j < n; ++j) {
+                if (done[j] || level[j] != lv) continue;
+                const Step& s = seq[j];
+                if (s.kind != s0.kind || s.stage != s0.stage) continue;
+                // LSTM launches come in a register-resident (H <= 64) and an L2 flavour
+                if ((s.kind == K_LSTM_F || s.kind == K_LSTM_B || s.kind == K_LSTM_T) && ((s.b > 64) != (s0.b > 64))) continue;
+                if (j != i && !mergeable) continue;
+                done[j] = 1;
+                for (int q = 0; q < s.count; ++q) {
+                    if (s.kind == K_GEMM) { GemmDesc g = gemms[s.first + q]; g.variant = gemm_variant(g); if (g.variant < 0) err = MST_ERR_UNSUPPORTED; s_gemms.push_back(g); }
+                    else if (s.kind == K_GATHER) s_gathers.push_back(gathers[s.first + q]);
+                    else if (s.kind == K_SEGRED) s_segreds.push_back(segreds[s.first + q]);
+                    else if (s.kind == K_LSTM_T || s.kind == K_LSTM_F || s.kind == K_LSTM_B) s_lstms.push_back(lstms[s.first + q]);
+                }
+                m.count += s.count;
+                if (s.a > m.a) m.a = s.a;
+                if (s.b > m.b) m.b = s.b;
+            }
+            out.push_back(m);
+        }
+    }
+}
+
+void mst_plan::schedule() {
+    std::vector<Step> fwd, bwd;
+    for (auto& op : ops) for (auto s : op.fwd) { s.stage = op.stage; fwd.push_back(s); }
+    for (size_t i = ops.size(); i-- > 0;) for (auto s : ops[i].bwd) { s.stage = ops[i].stage; bwd.push_back(s); }
+    schedule_pass(fwd, sched[0]);
+    schedule_pass(bwd, sched[1]);
+}
+
 template <class D>
 static int up(const std::vector<D>& v, D** dev) {
     *dev = nullptr;
@@ -636,7 +839,7 @@ static int up(const std::vector<D>& v, D** dev) {
 
 int mst_plan::upload() {
     int e = 0;
-    e |= up(gemms, &d_gemms); e |= up(gathers, &d_gathers); e |= up(segreds, &d_segreds); e |= up(lstms, &d_lstms);
+    e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
     e |= up(combines, &d_combines); e |= up(notes, &d_notes);
     for (int s = 0; s < 3; ++s) {
         e |= up(slabs[s], &d_slabs[s]);
@@ -654,6 +857,7 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
     p->d = *d; p->z = mst_sizes(*d);
     build_params(*d, p->z, p->pt);
     p->build();
+    if (!p->err) p->schedule();
     if (p->err) { *status = p->err; delete p; return nullptr; }
     int e = p->upload();
     if (e) { *status = e; mst_plan_destroy(p); return nullptr; }
@@ -683,9 +887,9 @@ extern "C" int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t*
 extern "C" int32_t mst_plan_launch_count(const mst_plan* p, int32_t mask, int32_t backward) {
     if (!p) return MST_ERR_ARG;
     int n = 0;
-    for (auto& op : p->ops) {
-        if (!(op.stage & mask)) continue;
-        for (auto& s : (backward ? op.bwd : op.fwd)) n += (s.kind == K_COMB_F || s.kind == K_COMB_B || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
+    for (auto& s : p->sched[backward ? 1 : 0]) {
+        if (!(s.stage & mask)) continue;
+        n += (s.kind == K_COMB_F || s.kind == K_COMB_B || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
     }
     if (backward) for (int s = 0; s < 3; ++s) if ((mask >> s) & 1) n += 1;
     return n;
@@ -702,7 +906,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(gemm_variant(p->gemms[s.first]), p->d_gemms + s.first, s.count, s.a, s.b, b, st);
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, s.b, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
@@ -723,12 +927,10 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
     if (!p || !params || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, nullptr, ws, pitched, unpitched);
-    for (auto& op : p->ops) {
-        if (!(op.stage & mask)) continue;
-        for (auto& s : op.fwd) {
-            int e = run_step(p, s, b, (hipStream_t)stream);
-            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
-        }
+    for (auto& s : p->sched[0]) {
+        if (!(s.stage & mask)) continue;
+        int e = run_step(p, s, b, (hipStream_t)stream);
+        if (e) return e < 0 ? e : MST_ERR_LAUNCH;
     }
     return MST_OK;
 }
@@ -749,13 +951,10 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     if (!p || !params || !gparams || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
-    for (size_t i = p->ops.size(); i-- > 0;) {
-        const Op& op = p->ops[i];
-        if (!(op.stage & mask)) continue;
-        for (auto& s : op.bwd) {
-            int e = run_step(p, s, b, (hipStream_t)stream);
-            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
-        }
+    for (auto& s : p->sched[1]) {
+        if (!(s.stage & mask)) continue;
+        int e = run_step(p, s, b, (hipStream_t)stream);
+        if (e) return e < 0 ? e : MST_ERR_LAUNCH;
     }
     for (int s = 2; s >= 0; --s) {
         if (!((mask >> s) & 1)) continue;
@@ -811,24 +1010,24 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
     switch (s.kind) {
     case K_GEMM:
         for (int i = 0; i < s.count; ++i) {
-            const GemmDesc& g = p->gemms[s.first + i];
+            const GemmDesc& g = p->s_gemms[s.first + i];
             f += 2.0 * g.M * g.N * g.K;
             b += 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N);
         }
         break;
     case K_GATHER:
-        for (int i = 0; i < s.count; ++i) { const GatherDesc& g = p->gathers[s.first + i]; b += 8.0 * g.rows * g.K; }
+        for (int i = 0; i < s.count; ++i) { const GatherDesc& g = p->s_gathers[s.first + i]; b += 8.0 * g.rows * g.K; }
         break;
     case K_SEGRED:
         for (int i = 0; i < s.count; ++i) {
-            const SegRedDesc& r = p->segreds[s.first + i];
+            const SegRedDesc& r = p->s_segreds[s.first + i];
             const double rows = (double)r.d[0] * r.d[1] * r.d[2] * r.d[3];
             f += rows * r.width; b += 4.0 * (rows * r.width + 2.0 * r.nidx * r.width);
         }
         break;
     case K_LSTM_F: case K_LSTM_B:
         for (int i = 0; i < s.count; ++i) {
-            const LstmDesc& l = p->lstms[s.first + i];
+            const LstmDesc& l = p->s_lstms[s.first + i];
             f += (double)l.B * l.S * (8.0 * l.H * l.H + 30.0 * l.H);
             b += 4.0 * ((double)l.B * l.S * 11.0 * l.H + 4.0 * l.H * l.H);
         }
@@ -864,7 +1063,7 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
 extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t backward) {
     if (!p) return MST_ERR_ARG;
     int n = 0;
-    for (auto& op : p->ops) if (op.stage & mask) n += (int)(backward ? op.bwd.size() : op.fwd.size());
+    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) ++n;
     return n;
 }
 
@@ -873,16 +1072,15 @@ extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t 
 extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 5 per step */) {
     if (!p || !info) return MST_ERR_ARG;
     std::vector<const Step*> steps;
-    if (!backward) { for (auto& op : p->ops) if (op.stage & mask) for (auto& s : op.fwd) steps.push_back(&s); }
-    else { for (size_t i = p->ops.size(); i-- > 0;) if (p->ops[i].stage & mask) for (auto& s : p->ops[i].bwd) steps.push_back(&s); }
+    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
         int32_t* o = info + 5 * idx++;
         o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count;
-        if (s->kind == K_GEMM) { const GemmDesc& g = p->gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
-        else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
-        else if (s->kind == K_GATHER) { const GatherDesc& g = p->gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
-        else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
+        if (s->kind == K_GEMM) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
+        else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
+        else if (s->kind == K_GATHER) { const GatherDesc& g = p->s_gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
+        else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->s_segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
         else if (s->kind == K_COMB_F || s->kind == K_COMB_B) { const CombineDesc& c = p->combines[s->first]; o[0] = c.Cn; o[1] = c.rows; o[2] = c.cols; o[3] = c.nblk; }
     }
     return idx;
@@ -897,8 +1095,7 @@ extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t 
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MST_ERR_ALLOC;
     std::vector<const Step*> steps;
-    if (!backward) { for (auto& op : p->ops) if (op.stage & mask) for (auto& s : op.fwd) steps.push_back(&s); }
-    else { for (size_t i = p->ops.size(); i-- > 0;) if (p->ops[i].stage & mask) for (auto& s : p->ops[i].bwd) steps.push_back(&s); }
+    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
         run_step(p, *s, b, st);                       // warm
