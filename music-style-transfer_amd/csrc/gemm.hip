@@ -12,8 +12,9 @@
 // k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
 // float4 fragment reads).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
 // tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
-// descriptor, so independent small GEMMs share one launch; blockIdx.z is the split of the
-// reduction dimension for weight gradients (deterministic slabs, reduced later in order).
+// Independent GEMMs share one launch: the 1-D grid is the concatenation of every member's
+// (tile, k-split) workgroups; k-splits of weight gradients write deterministic slabs that are
+// reduced later in order.
 #include "mst_common.h"
 
 __device__ __forceinline__ float act_fwd(int act, float z, int col) {
@@ -95,7 +96,8 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
 }
 
 template <int AK, int BKIND, int OK, int AKF, int BKF>
-__device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, float (*As)[GEMM_BM + 4], float (*Bs)[GEMM_BN + 4]) {
+__device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
+                                          float (*As)[GEMM_BM + 4], float (*Bs)[GEMM_BN + 4]) {
     // 32x32 output tile per workgroup, 128-deep k-tile: wave w owns k rows [32w, 32w+32) of the
     // tile (in-block split-K), so the dependent k chain is K/128 steps and small problems still
     // spread over many workgroups; the four partial tiles are summed through LDS at the end.
@@ -104,10 +106,6 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, flo
     const int tid = threadIdx.x;
     const int M = d.M, N = d.N;
     const int tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-    const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
-    const int tile = blockIdx.x;
-    const int split = blockIdx.z;
-    if (tile >= tiles_m * tiles_n || split >= d.ksplit) return;   // block-uniform
     const gcptr baseA = (gcptr)(b.p[d.A.space] + d.A.off);
     const gcptr baseA2 = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
     const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
@@ -209,19 +207,25 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, flo
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
 // all small Linears of one dependency level — into a single launch.
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, Bases b) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, Bases b) {
     __shared__ float As[GEMM_BK][GEMM_BM + 4];
     __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
-    const GemmDesc& d = descs[blockIdx.y];          // uniform: read through the scalar cache
+    // flat 1-D grid: member y owns workgroups [blk_begin, blk_begin + tiles * ksplit)
+    int y = 0;
+    while (y + 1 < count && (int)blockIdx.x >= descs[y + 1].blk_begin) ++y;
+    const GemmDesc& d = descs[y];                    // uniform: read through the scalar cache
+    const int local = blockIdx.x - d.blk_begin;
+    const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
+    const int tile = local % ntile, split = local / ntile;
     switch (d.variant) {
-    case GV_LIN_FWD: gemm_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, As, Bs); break;
-    case GV_LIN_FWD_PERM: gemm_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, As, Bs); break;
-    case GV_LIN_DW: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, As, Bs); break;
-    case GV_LIN_DW_PERM: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, As, Bs); break;
-    case GV_LIN_DA: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, As, Bs); break;
-    case GV_CONV_FWD: gemm_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, As, Bs); break;
-    case GV_CONV_DW: gemm_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, As, Bs); break;
-    case GV_HH_DW: gemm_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, As, Bs); break;
+    case GV_LIN_FWD: gemm_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_FWD_PERM: gemm_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DW: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DW_PERM: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DA: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, tile, split, As, Bs); break;
+    case GV_CONV_FWD: gemm_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_CONV_DW: gemm_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs); break;
+    case GV_HH_DW: gemm_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
     default: break;
     }
 }
@@ -239,9 +243,9 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s) {
-    if (count <= 0) return 0;
-    hipLaunchKernelGGL(gemm_kernel, dim3(max_tiles, count, max_split), dim3(256), 0, s, dev_descs, b);
+int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b, hipStream_t s) {
+    if (count <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(gemm_kernel, dim3(total_blocks), dim3(256), 0, s, dev_descs, count, b);
     return (int)hipGetLastError();
 }
 

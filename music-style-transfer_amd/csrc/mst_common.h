@@ -74,6 +74,7 @@ struct OutSpec {
 struct GemmDesc {
     int32_t M, N, K, ksplit;
     int32_t variant;     // GV_* instantiation (filled by the plan from the operand kinds)
+    int32_t blk_begin;   // first workgroup of this member inside its (merged) launch
     Operand A, B;
     OutSpec out;
 };
@@ -162,7 +163,7 @@ Sizes mst_sizes(const mst_dims& d);
 enum { GV_LIN_FWD, GV_LIN_FWD_PERM, GV_LIN_DW, GV_LIN_DW_PERM, GV_LIN_DA, GV_CONV_FWD, GV_CONV_DW, GV_HH_DW };
 int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipStream_t s);
 int gemm_variant(const GemmDesc& g);
-int launch_gemm(const GemmDesc* dev_descs, int count, int max_tiles, int max_split, Bases b, hipStream_t s);
+int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b, hipStream_t s);
 int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s);
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);

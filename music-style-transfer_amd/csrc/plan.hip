@@ -556,7 +556,7 @@ void mst_plan::build() {
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
         n.out_off = mel_c.off; n.g_out_off = mel_c.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
         const int nw = z.ME_CW * NPF + z.ME_CW + z.MEL * (z.MEL + z.ME_CW) + z.MEL;
-        n.nblk = P_ < 128 ? P_ : 128; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        n.nblk = P_ < 256 ? P_ : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = E;
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
@@ -609,7 +609,7 @@ void mst_plan::build() {
         n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
         const int qf = Q_ * NF;
-        n.nblk = qf < 256 ? qf : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        n.nblk = qf < 512 ? qf : 512; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
@@ -815,6 +815,15 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 if (s.a > m.a) m.a = s.a;
                 if (s.b > m.b) m.b = s.b;
             }
+            if (m.kind == K_GEMM) {      // flat grid: concatenate every member's (tile, k-split) workgroups
+                int total = 0;
+                for (int q = 0; q < m.count; ++q) {
+                    GemmDesc& g = s_gemms[m.first + q];
+                    g.blk_begin = total;
+                    total += tiles(g.M, g.N) * g.ksplit;
+                }
+                m.a = total; m.b = 0;
+            }
             out.push_back(m);
         }
     }
@@ -906,7 +915,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, s.b, b, st);
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
