@@ -153,34 +153,39 @@ class Plan:
             self._slots[name] = (off.value, goff.value, numel.value)
         return self._slots[name]
 
-    def view(self, name, shape=None):
+    def new_ws(self):
+        """A fresh workspace for this plan (one per in-flight forward whose backward is still pending)."""
+        return torch.zeros_like(self.ws)
+
+    def view(self, name, shape=None, ws=None):
         off, _, n = self.slot(name)
-        t = self.ws[off:off + n]
+        t = (self.ws if ws is None else ws)[off:off + n]
         return t.view(*shape) if shape is not None else t
 
-    def grad(self, name, shape=None):
+    def grad(self, name, shape=None, ws=None):
         _, goff, n = self.slot(name)
-        t = self.ws[goff:goff + n]
+        t = (self.ws if ws is None else ws)[goff:goff + n]
         return t.view(*shape) if shape is not None else t
 
-    def set_inputs(self, mode=None, bpm=None, instr=None, used=None, bpm_target=None):
+    def set_inputs(self, mode=None, bpm=None, instr=None, used=None, bpm_target=None, ws=None):
         for name, t in (('mode', mode), ('bpm', bpm), ('instr', instr), ('used_instruments', used), ('bpm_target', bpm_target)):
             if t is not None:
-                self.view(name).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
+                self.view(name, ws=ws).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
 
     def launch_count(self, mask=STAGE_ALL, backward=False):
         return self.lib.mst_plan_launch_count(self.handle, mask, int(backward))
 
-    def forward(self, mask, params, pitched, unpitched):
-        check(self.lib.mst_forward(self.handle, mask, ptr(params), ptr(self.ws), ptr(pitched), ptr(unpitched),
-                                   current_stream(self.device)), 'mst_forward')
+    def forward(self, mask, params, pitched, unpitched, ws=None):
+        check(self.lib.mst_forward(self.handle, mask, ptr(params), ptr(self.ws if ws is None else ws), ptr(pitched),
+                                   ptr(unpitched), current_stream(self.device)), 'mst_forward')
 
-    def backward(self, mask, params, gparams, pitched, unpitched):
-        check(self.lib.mst_backward(self.handle, mask, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched),
-                                    ptr(unpitched), current_stream(self.device)), 'mst_backward')
+    def backward(self, mask, params, gparams, pitched, unpitched, ws=None):
+        check(self.lib.mst_backward(self.handle, mask, ptr(params), ptr(gparams), ptr(self.ws if ws is None else ws),
+                                    ptr(pitched), ptr(unpitched), current_stream(self.device)), 'mst_backward')
 
-    def zero_grads(self, mask):
-        check(self.lib.mst_zero_grads(self.handle, mask, ptr(self.ws), current_stream(self.device)), 'mst_zero_grads')
+    def zero_grads(self, mask, ws=None):
+        check(self.lib.mst_zero_grads(self.handle, mask, ptr(self.ws if ws is None else ws), current_stream(self.device)),
+              'mst_zero_grads')
 
     def time_steps(self, mask, backward, params, gparams, pitched, unpitched, reps=20):
         """[(kind, avg_ms, flops, bytes)] per launch step (HIP events on the current stream)."""
@@ -195,9 +200,9 @@ class Plan:
             check(got if got < 0 else -1, 'mst_plan_time_steps')
         return list(zip(kind.tolist(), ms.tolist(), fl.tolist(), by.tolist()))
 
-    def train_iteration(self, params, gparams, pitched, unpitched, losses=None):
-        check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched),
-                                           ptr(unpitched), ptr(losses), current_stream(self.device)),
+    def train_iteration(self, params, gparams, pitched, unpitched, losses=None, ws=None):
+        check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws if ws is None else ws),
+                                           ptr(pitched), ptr(unpitched), ptr(losses), current_stream(self.device)),
               'mst_train_iteration')
 
 

@@ -1,0 +1,487 @@
+"""MI355X-native `style.model`: the reference's Python surface (style/model.py:28-997) over the HIP
+hot path in libmst_amd.so.
+
+What is kept, so that train-model.py:15-28,54-126 and style/style_transfer.py:17,67-131 run unchanged:
+the nine module classes with their constructor signatures and the same `nn.Linear / nn.Conv1d /
+LSTM / Distributed` children under the same attribute names (=> identical state_dict keys,
+parameter order, seed-108 initialisation and pickle class paths), `StyleTransferModel` with
+`extract_style / predict_song_info / apply_style / forward`, `get_total_loss` (including the
+positional bpm-before-mode contract of train-model.py:115-122), `hard_output`, `device`.
+
+What is different: no module executes torch ops.  The children are parameter containers; the
+four model methods and the loss are `torch.autograd.Function`s that borrow `data_ptr()`s and
+enqueue hand-written HIP kernels through the C ABI (include/mst_amd.h).  There is no CPU
+fallback: without the library or without a GPU tensor the calls raise.
+"""
+import collections
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from style import _native
+from style.utils.pytorch import Distributed, LSTM
+
+epsilon = 1e-7
+n_beat_fractions = 10
+n_pitched_features = 5
+n_unpitched_features = 2
+n_octaves = 8
+n_scale_degrees = 7
+n_pitched_notes = n_octaves * n_scale_degrees
+n_unpitched_notes = 47
+n_modes = 2
+min_bpm = 50
+max_bpm = 200
+bpm_range = max_bpm - min_bpm
+mean_type = 'quadratic'
+device = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+_DEFAULT_WIDTHS = dict(beat=64, bar=128, nrf=8, style=256, melody=8, rhythm=32, instr=51, n_instruments=41)
+# Distributed(depth) of the wrapped children (style/model.py:53,68,119,467)
+_DEPTH = {('pitched_channels_encoder', 'beats_conv'): 3, ('pitched_channels_encoder', 'beats_lstm'): 2,
+          ('unpitched_channels_encoder', 'beats_lstm'): 2, ('song_info_model', 'beats_lstm'): 1}
+
+
+def get_mean_size(*values, factor=1):
+    return math.ceil(np.mean(values) * factor)
+
+
+def _dims(C=1, R=1, T=1, unpitched=True, **widths):
+    w = dict(_DEFAULT_WIDTHS)
+    w.update(widths)
+    return _native.Dims(C=C, R=R, T=T, beat=w['beat'], bar=w['bar'], nrf=w['nrf'], style=w['style'], melody=w['melody'],
+                        rhythm=w['rhythm'], instr=w['instr'], n_instruments=w['n_instruments'], has_unpitched=int(unpitched))
+
+
+class _Container(nn.Module):
+    """A sub-module of the reference as a parameter container.  Children are created from the C
+    ABI's parameter table (mst_param_info), in its order, so Python and HIP agree by construction."""
+    _prefix = None
+
+    def _build(self, **widths):
+        self._widths = widths
+        table = _native.get().param_table(_dims(**widths))
+        groups = collections.OrderedDict()
+        for name, _, shape in table:
+            if not name.startswith(self._prefix + '.'):
+                continue
+            rest = name[len(self._prefix) + 1:]
+            child, leaf = rest.split('.', 1)
+            groups.setdefault(child, {})[leaf] = shape
+        for child, leaves in groups.items():
+            wrapped = any(k.startswith('module.') for k in leaves)
+            leaves = {k[len('module.'):] if wrapped else k: v for k, v in leaves.items()}
+            if 'weight_ih_l0' in leaves:
+                four_h, n_in = leaves['weight_ih_l0']
+                mod = LSTM(input_size=n_in, hidden_size=four_h // 4, num_layers=1, batch_first=True,
+                           bidirectional='weight_ih_l0_reverse' in leaves)
+            elif len(leaves['weight']) == 3:
+                oc, ic, k = leaves['weight']
+                mod = nn.Conv1d(in_channels=ic, out_channels=oc, kernel_size=k, stride=n_scale_degrees, padding=4)
+            else:
+                n_out, n_in = leaves['weight']
+                mod = nn.Linear(in_features=n_in, out_features=n_out)
+            if wrapped:
+                mod = Distributed(mod, depth=_DEPTH[(self._prefix, child)])
+            setattr(self, child, mod)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            f'{type(self).__name__} is a parameter container on the MI355X path: its arithmetic is fused into the HIP '
+            'kernels behind StyleTransferModel.extract_style / predict_song_info / apply_style / forward.')
+
+
+class PitchedChannelsEncoder(_Container):
+    _prefix = 'pitched_channels_encoder'
+
+    def __init__(self, beat_size, bar_size, instrument_size):
+        super().__init__()
+        assert bar_size % 2 == 0
+        self._build(beat=beat_size, bar=bar_size, instr=instrument_size)
+
+
+class UnpitchedChannelsEncoder(_Container):
+    _prefix = 'unpitched_channels_encoder'
+
+    def __init__(self, beat_size, bar_size):
+        super().__init__()
+        assert bar_size % 2 == 0
+        self._build(beat=beat_size, bar=bar_size)
+
+
+class StyleEncoder(_Container):
+    _prefix = 'style_encoder'
+
+    def __init__(self, style_size, bar_size, instrument_size):
+        super().__init__()
+        self._build(style=style_size, bar=bar_size, instr=instrument_size)
+
+
+class MelodyEncoder(_Container):
+    _prefix = 'melody_encoder'
+
+    def __init__(self, melody_size, beat_size, bar_size, instrument_size):
+        super().__init__()
+        self._build(melody=melody_size, beat=beat_size, bar=bar_size, instr=instrument_size)
+
+
+class PitchedRhythmEncoder(_Container):
+    _prefix = 'pitched_rhythm_encoder'
+
+    def __init__(self, rhythm_size, beat_size, bar_size, instrument_size):
+        super().__init__()
+        self._build(rhythm=rhythm_size, beat=beat_size, bar=bar_size, instr=instrument_size)
+
+
+class UnpitchedRhythmEncoder(_Container):
+    _prefix = 'unpitched_rhythm_encoder'
+
+    def __init__(self, rhythm_size, beat_size, bar_size):
+        super().__init__()
+        self._build(rhythm=rhythm_size, beat=beat_size, bar=bar_size)
+
+
+class SongInfoModel(_Container):
+    _prefix = 'song_info_model'
+
+    def __init__(self, n_rhythm_features, style_size, rhythm_size, n_instruments):
+        super().__init__()
+        self._build(nrf=n_rhythm_features, style=style_size, rhythm=rhythm_size, n_instruments=n_instruments)
+
+
+class PitchedStyleApplier(_Container):
+    _prefix = 'pitched_style_applier'
+
+    def __init__(self, style_size, melody_size, rhythm_size, instrument_size):
+        super().__init__()
+        self._build(style=style_size, melody=melody_size, rhythm=rhythm_size, instr=instrument_size)
+
+
+class UnpitchedStyleApplier(_Container):
+    _prefix = 'unpitched_style_applier'
+
+    def __init__(self, style_size, rhythm_size):
+        super().__init__()
+        self._build(style=style_size, rhythm=rhythm_size)
+
+
+def _f32c(t, dev):
+    return torch.as_tensor(t, dtype=torch.float32, device=dev).contiguous()
+
+
+class StyleTransferModel(nn.Module):
+    def __init__(self, pitched_channels_encoder, unpitched_channels_encoder, style_encoder, melody_encoder,
+                 pitched_rhythm_encoder, unpitched_rhythm_encoder, song_info_model, pitched_style_applier,
+                 unpitched_style_applier):
+        super().__init__()
+        self.pitched_channels_encoder = pitched_channels_encoder
+        self.unpitched_channels_encoder = unpitched_channels_encoder
+        self.style_encoder = style_encoder
+        self.melody_encoder = melody_encoder
+        self.pitched_rhythm_encoder = pitched_rhythm_encoder
+        self.unpitched_rhythm_encoder = unpitched_rhythm_encoder
+        self.song_info_model = song_info_model
+        self.pitched_style_applier = pitched_style_applier
+        self.unpitched_style_applier = unpitched_style_applier
+        widths = {}
+        for _, child in self.named_children():
+            for k, v in child._widths.items():
+                if widths.setdefault(k, v) != v:
+                    raise ValueError(f'sub-modules disagree on {k}_size: {widths[k]} vs {v}')
+        self._widths = widths
+        self._flat = self._gflat = None
+        self._offsets = None
+
+    # ---- flat parameter / gradient buffers -------------------------------------------------
+    def _sync_flat(self):
+        """Point every Parameter's storage into ONE flat fp32 buffer laid out as the C ABI expects
+        (model.parameters() order).  Re-done if the parameters moved (.to(), load_state_dict of new tensors)."""
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        if dev.type != 'cuda':
+            raise _native.MstError('the MI355X path needs the model on a GPU (model.to("cuda")); there is no CPU fallback')
+        if self._flat is not None and self._flat.device == dev and all(
+                p.data_ptr() == self._flat.data_ptr() + 4 * off for (_, p), off in zip(named, self._offsets)):
+            return
+        table = _native.get().param_table(_dims(**self._widths))
+        if [n for n, _ in named] != [n for n, _, _ in table]:
+            raise _native.MstError('parameter names/order differ from the C ABI layout')
+        flat = torch.empty(_native.get().param_floats(_dims(**self._widths)), dtype=torch.float32, device=dev)
+        for (name, p), (_, off, shape) in zip(named, table):
+            if tuple(p.shape) != shape:
+                raise _native.MstError(f'{name}: shape {tuple(p.shape)} != {shape}')
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(shape)
+        self._flat, self._gflat = flat, torch.zeros_like(flat)
+        self._offsets = [off for _, off, _ in table]
+
+    def _grad_target(self):
+        """Where backward accumulates: the flat gradient buffer, aliased by every p.grad."""
+        params = list(self.parameters())
+        mine = [p.grad is not None and p.grad.data_ptr() == self._gflat.data_ptr() + 4 * off
+                for p, off in zip(params, self._offsets)]
+        if not any(p.grad is not None for p in params):
+            self._gflat.zero_()             # zero_grad(set_to_none=True) dropped the aliases
+        elif not all(mine):
+            raise _native.MstError('p.grad was replaced by foreign tensors; use zero_grad() or keep the aliased grads')
+        return self._gflat
+
+    def _publish_grads(self):
+        for p, off in zip(self.parameters(), self._offsets):
+            if p.grad is None:
+                p.grad = self._gflat[off:off + p.numel()].view(p.shape)
+
+    def _plan(self, C, R, T, unpitched, dev):
+        return _native.get().plan(_dims(C=C, R=R, T=T, unpitched=unpitched, **self._widths), dev)
+
+    def _anchor(self):
+        self._sync_flat()
+        return next(self.parameters())
+
+    # ---- reference surface (style/model.py:751-793) ----------------------------------------
+    def extract_style(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
+        return _Extract.apply(self, self._anchor(), mode, bpm, pitched_channels, instruments_features, unpitched_channels)
+
+    def predict_song_info(self, style, rhythm):
+        return _Predict.apply(self, self._anchor(), style, rhythm)
+
+    def apply_style(self, style, melody, rhythm, instruments_features, unpitched=False):
+        x_pitched, x_unpitched = _Apply.apply(self, self._anchor(), style, melody, rhythm, instruments_features, bool(unpitched))
+        return x_pitched, (x_unpitched if unpitched else None)
+
+    def forward(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
+        ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), mode, bpm, pitched_channels, instruments_features,
+                                            unpitched_channels)
+        return (ip, mp, bp), xp, (xu if unpitched_channels is not None else None)
+
+
+def _shapes(model, C, R, T):
+    w = dict(_DEFAULT_WIDTHS)
+    w.update(model._widths)
+    return dict(style=(1, w['style']), melody=(1, R, T, 10, 56, w['melody']), rhythm=(1, R, T, 10, w['rhythm']),
+                instruments_pred=(1, w['n_instruments']), mode_pred=(1, 2), bpm_pred=(1,),
+                pitched_pred=(1, C, R, T, 10, 56, 5), unpitched_pred=(1, 1, R, T, 10, 47, 2))
+
+
+def _seed(plan, ws, name, g):
+    slot = plan.grad(name, ws=ws)
+    if g is None:
+        slot.zero_()
+    else:
+        slot.copy_(g.reshape(-1))
+
+
+class _StageFn(torch.autograd.Function):
+    """Common plumbing: one workspace per forward whose backward is pending."""
+
+    @staticmethod
+    def _ws(plan):
+        return plan.new_ws() if torch.is_grad_enabled() else plan.ws
+
+
+class _Extract(_StageFn):
+    @staticmethod
+    def forward(ctx, model, anchor, mode, bpm, pitched, instr, unpitched):
+        dev = anchor.device
+        pitched = _f32c(pitched, dev)
+        unpitched = None if unpitched is None else _f32c(unpitched, dev)
+        _, C, R, T = pitched.shape[:4]
+        plan = model._plan(C, R, T, unpitched is not None, dev)
+        ws = _StageFn._ws(plan)
+        plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instr, dev), ws=ws)
+        plan.forward(_native.STAGE_EXTRACT, model._flat, pitched, unpitched, ws=ws)
+        shp = _shapes(model, C, R, T)
+        ctx.stuff = (model, plan, ws, pitched, unpitched)
+        return tuple(plan.view(k, shp[k], ws=ws).clone() for k in ('style', 'melody', 'rhythm'))
+
+    @staticmethod
+    def backward(ctx, g_style, g_melody, g_rhythm):
+        model, plan, ws, pitched, unpitched = ctx.stuff
+        plan.zero_grads(_native.STAGE_EXTRACT, ws=ws)
+        for k, g in (('style', g_style), ('melody', g_melody), ('rhythm', g_rhythm)):
+            _seed(plan, ws, k, g)
+        plan.backward(_native.STAGE_EXTRACT, model._flat, model._grad_target(), pitched, unpitched, ws=ws)
+        model._publish_grads()
+        return (None,) * 7
+
+
+class _Predict(_StageFn):
+    @staticmethod
+    def forward(ctx, model, anchor, style, rhythm):
+        dev = anchor.device
+        R, T = rhythm.shape[1:3]
+        plan = model._plan(1, R, T, False, dev)
+        ws = _StageFn._ws(plan)
+        plan.view('style', ws=ws).copy_(_f32c(style, dev).reshape(-1))
+        plan.view('rhythm', ws=ws).copy_(_f32c(rhythm, dev).reshape(-1))
+        plan.forward(_native.STAGE_INFO, model._flat, None, None, ws=ws)
+        shp = _shapes(model, 1, R, T)
+        ctx.stuff = (model, plan, ws)
+        return tuple(plan.view(k, shp[k], ws=ws).clone() for k in ('instruments_pred', 'mode_pred', 'bpm_pred'))
+
+    @staticmethod
+    def backward(ctx, g_instr, g_mode, g_bpm):
+        model, plan, ws = ctx.stuff
+        plan.zero_grads(_native.STAGE_INFO, ws=ws)
+        for k in ('style', 'rhythm'):
+            plan.grad(k, ws=ws).zero_()
+        for k, g in (('instruments_pred', g_instr), ('mode_pred', g_mode), ('bpm_pred', g_bpm)):
+            _seed(plan, ws, k, g)
+        plan.backward(_native.STAGE_INFO, model._flat, model._grad_target(), None, None, ws=ws)
+        model._publish_grads()
+        shp = _shapes(model, 1, *[int(v) for v in (plan.dims.R, plan.dims.T)])
+        return None, None, plan.grad('style', shp['style'], ws=ws).clone(), plan.grad('rhythm', shp['rhythm'], ws=ws).clone()
+
+
+class _Apply(_StageFn):
+    @staticmethod
+    def forward(ctx, model, anchor, style, melody, rhythm, instr, unpitched):
+        dev = anchor.device
+        instr = _f32c(instr, dev)
+        C = instr.shape[1]
+        R, T = rhythm.shape[1:3]
+        plan = model._plan(C, R, T, unpitched, dev)
+        ws = _StageFn._ws(plan)
+        plan.set_inputs(instr=instr, ws=ws)
+        for k, t in (('style', style), ('melody', melody), ('rhythm', rhythm)):
+            plan.view(k, ws=ws).copy_(_f32c(t, dev).reshape(-1))
+        plan.forward(_native.STAGE_APPLY, model._flat, None, None, ws=ws)
+        shp = _shapes(model, C, R, T)
+        ctx.stuff = (model, plan, ws, unpitched)
+        xp = plan.view('pitched_pred', shp['pitched_pred'], ws=ws).clone()
+        xu = plan.view('unpitched_pred', shp['unpitched_pred'], ws=ws).clone() if unpitched else xp.new_zeros(1)
+        return xp, xu
+
+    @staticmethod
+    def backward(ctx, g_xp, g_xu):
+        model, plan, ws, unpitched = ctx.stuff
+        plan.zero_grads(_native.STAGE_APPLY, ws=ws)
+        for k in ('style', 'melody', 'rhythm'):
+            plan.grad(k, ws=ws).zero_()
+        _seed(plan, ws, 'pitched_pred', g_xp)
+        if unpitched:
+            _seed(plan, ws, 'unpitched_pred', g_xu)
+        plan.backward(_native.STAGE_APPLY, model._flat, model._grad_target(), None, None, ws=ws)
+        model._publish_grads()
+        shp = _shapes(model, plan.dims.C, plan.dims.R, plan.dims.T)
+        return (None, None) + tuple(plan.grad(k, shp[k], ws=ws).clone() for k in ('style', 'melody', 'rhythm')) + (None, None)
+
+
+class _Forward(_StageFn):
+    """extract_style + predict_song_info + apply_style in one workspace (the training path)."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, mode, bpm, pitched, instr, unpitched):
+        dev = anchor.device
+        pitched = _f32c(pitched, dev)
+        unpitched = None if unpitched is None else _f32c(unpitched, dev)
+        _, C, R, T = pitched.shape[:4]
+        U = unpitched is not None
+        plan = model._plan(C, R, T, U, dev)
+        ws = _StageFn._ws(plan)
+        plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instr, dev), ws=ws)
+        plan.forward(_native.STAGE_ALL, model._flat, pitched, unpitched, ws=ws)
+        shp = _shapes(model, C, R, T)
+        ctx.stuff = (model, plan, ws, pitched, unpitched)
+        keys = ['instruments_pred', 'mode_pred', 'bpm_pred', 'pitched_pred']
+        outs = [plan.view(k, shp[k], ws=ws).clone() for k in keys]
+        outs.append(plan.view('unpitched_pred', shp['unpitched_pred'], ws=ws).clone() if U else outs[0].new_zeros(1))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_instr, g_mode, g_bpm, g_xp, g_xu):
+        model, plan, ws, pitched, unpitched = ctx.stuff
+        plan.zero_grads(_native.STAGE_ALL, ws=ws)
+        for k, g in (('instruments_pred', g_instr), ('mode_pred', g_mode), ('bpm_pred', g_bpm), ('pitched_pred', g_xp)):
+            _seed(plan, ws, k, g)
+        if unpitched is not None:
+            _seed(plan, ws, 'unpitched_pred', g_xu)
+        plan.backward(_native.STAGE_ALL, model._flat, model._grad_target(), pitched, unpitched, ws=ws)
+        model._publish_grads()
+        return (None,) * 7
+
+
+# ---- losses (style/model.py:847-997) --------------------------------------------------------
+class _Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pp, pt, up, ut, il, it, ml, mt, bp, bt, normalize):
+        lib = _native.get().lib
+        dev = pp.device
+        if dev.type != 'cuda':
+            raise _native.MstError('get_total_loss needs GPU tensors; there is no CPU fallback')
+        pp, pt, il, it, ml, mt, bp, bt = (_f32c(t, dev) for t in (pp, pt, il, it, ml, mt, bp, bt))
+        has_u = up is not None and ut is not None
+        up, ut = (_f32c(up, dev), _f32c(ut, dev)) if has_u else (None, None)
+        losses = torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev)
+        saved = torch.empty(_native.LOSS_SAVED, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.mst_loss_scratch_floats(), dtype=torch.float32, device=dev)
+        n_p = pp.numel() // 5
+        n_u = up.numel() // 2 if has_u else 0
+        P = _native.ptr
+        _native.check(lib.mst_total_loss_fwd(P(pp), P(pt), n_p, P(up), P(ut), n_u, P(il), P(it), il.numel(), P(ml), P(mt),
+                                             P(bp), P(bt), int(normalize), P(losses), P(saved), P(scratch),
+                                             _native.current_stream(dev)), 'mst_total_loss_fwd')
+        ctx.stuff = (pp, pt, up, ut, il, it, ml, mt, bp, bt, saved, n_p, n_u)
+        return losses
+
+    @staticmethod
+    def backward(ctx, gl):
+        pp, pt, up, ut, il, it, ml, mt, bp, bt, saved, n_p, n_u = ctx.stuff
+        lib = _native.get().lib
+        dev = pp.device
+        gl = torch.nan_to_num(_f32c(gl, dev))
+        g_pp, g_il, g_ml, g_bp = (torch.empty_like(t) for t in (pp, il, ml, bp))
+        g_up = torch.empty_like(up) if up is not None else None
+        P = _native.ptr
+        _native.check(lib.mst_total_loss_bwd(P(pp), P(pt), n_p, P(up), P(ut), n_u, P(il), P(it), il.numel(), P(ml), P(mt),
+                                             P(bp), P(bt), P(saved), P(gl), P(g_pp), P(g_up), P(g_il), P(g_ml), P(g_bp),
+                                             _native.current_stream(dev)), 'mst_total_loss_bwd')
+        return g_pp, None, g_up, None, g_il, None, g_ml, None, g_bp, None, None
+
+
+def get_total_loss(instruments_pred, instruments_target, mode_pred, mode_target, bpm_pred, bpm_target,
+                   pitched_pred, pitched_target, unpitched_pred=None, unpitched_target=None, normalize=False):
+    """Same nested dict as the reference (style/model.py:944-996).  Positional contract preserved: the
+    third/fourth slots are consumed as (bpm prediction, bpm target) and the fifth/sixth as (mode logits,
+    one-hot mode) — the reference's pack/unpack swap at :900-901 vs :976-977, which is how
+    train-model.py:115-122 calls it (bpm before mode)."""
+    dev = pitched_pred.device
+    bpm_p, bpm_t, mode_p, mode_t = mode_pred, mode_target, bpm_pred, bpm_target
+    bpm_t = torch.as_tensor(bpm_t, dtype=torch.float32, device=dev).reshape(-1)[:1]
+    L = _Loss.apply(pitched_pred, pitched_target, unpitched_pred if unpitched_target is not None else None,
+                    unpitched_target, instruments_pred, instruments_target, mode_p, mode_t, bpm_p.reshape(-1), bpm_t,
+                    bool(normalize))
+    k = {name: i for i, name in enumerate(_native.LOSS_KEYS)}
+    pitched = dict(total=L[k['channels_loss_pitched_total']], notes_loss=L[k['channels_loss_pitched_notes_loss']],
+                   velocity_loss=L[k['channels_loss_pitched_velocity_loss']],
+                   duration_loss=L[k['channels_loss_pitched_duration_loss']],
+                   accidentals_loss=L[k['channels_loss_pitched_accidentals_loss']])
+    unpitched = None
+    if unpitched_target is not None:
+        unpitched = dict(total=L[k['channels_loss_unpitched_total']], notes_loss=L[k['channels_loss_unpitched_notes_loss']],
+                         velocity_loss=L[k['channels_loss_unpitched_velocity_loss']],
+                         duration_loss=L[k['channels_loss_unpitched_duration_loss']])
+    one = lambda name: L[k[name]:k[name] + 1]      # shape (1,), like the reference's bpm-derived leaves
+    return dict(
+        total=one('total'),
+        channels_loss=dict(total=L[k['channels_loss_total']], pitched=pitched, unpitched=unpitched),
+        song_info_loss=dict(total=one('song_info_loss_total'), instruments_loss=L[k['song_info_loss_instruments_loss']],
+                            mode_loss=L[k['song_info_loss_mode_loss']], bpm_loss=one('song_info_loss_bpm_loss')),
+    )
+
+
+def hard_output(x):
+    """style/model.py:818-832 — like the reference it also zeroes sub-threshold velocities of `x` in place."""
+    if x.device.type != 'cuda':
+        raise _native.MstError('hard_output needs a GPU tensor; there is no CPU fallback')
+    nfeat = x.shape[-1]
+    work = x if (x.is_contiguous() and x.dtype == torch.float32) else x.detach().float().contiguous()
+    out = torch.empty_like(work)
+    _native.check(_native.get().lib.mst_hard_output(_native.ptr(work.detach()), _native.ptr(out), work.numel() // nfeat, nfeat,
+                                                    _native.current_stream(x.device)), 'mst_hard_output')
+    if work is not x:
+        with torch.no_grad():
+            x[..., 1] = work[..., 1].to(x.dtype)
+    return out

@@ -1,0 +1,184 @@
+"""-m gpu: the reference's Python surface (style.model) on an MI355X against fixtures produced by the
+reference itself: forward/loss/backward through autograd, torch.optim.Adam and the fused Adam, the
+three stage methods, the seed-108 full-width model, and a 6-iteration / 3-optimizer-step trajectory."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import style_oracle as so
+from oracle.synth import synth_clip
+from simutil import GOLDEN, rel
+from test_host_surface import FULL, SMALL, build_model
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def to_dev(clip):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in clip.items()}
+
+
+def reference_call(model, clip):
+    """train-model.py:113-123, verbatim argument order (bpm before mode)."""
+    import style.model as m
+    (ip, mp, bp), xp, xu = model(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+    losses = m.get_total_loss(ip, clip['used_instruments'], bp, clip['bpm_int'], mp, clip['mode'], xp, clip['pitched'],
+                              xu, clip['unpitched'], normalize=True)
+    return (ip, mp, bp, xp, xu), losses
+
+
+def flat(d, prefix=''):
+    out = {}
+    for k, v in d.items():
+        if v is None:
+            continue
+        if isinstance(v, dict):
+            out.update(flat(v, prefix + k + '_'))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def load_small(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    model = build_model(SMALL)
+    model.load_state_dict({k: torch.from_numpy(z['p0/' + k]) for k in model.state_dict()})
+    return z, model.to(DEV)
+
+
+@pytest.mark.parametrize('name,fused', [('small_unpitched', False), ('small_unpitched', True), ('small_pitched_only', False)])
+def test_train_loop_body_matches_reference(name, fused):
+    from style.optim import FusedAdam
+    z, model = load_small(name)
+    C, R, T = (int(v) for v in z['crt'])
+    unp = bool(z['unpitched'])
+    opt = FusedAdam(model) if fused else torch.optim.Adam(model.parameters(), lr=.01)
+    clip = to_dev(synth_clip(0, C, R, T, unp, density=float(z['density'])))
+    (ip, mp, bp, xp, xu), losses = reference_call(model, clip)
+    assert rel(xp.detach().cpu(), z['out/pitched']) < 1e-4 and rel(ip.detach().cpu(), z['out/instruments']) < 1e-4
+    assert rel(mp.detach().cpu(), z['out/mode']) < 1e-4 and rel(bp.detach().cpu(), z['out/bpm']) < 1e-4
+    if unp:
+        assert rel(xu.detach().cpu(), z['out/unpitched']) < 1e-4
+    else:
+        assert xu is None and losses['channels_loss']['unpitched'] is None
+    assert losses['total'].shape == (1,)
+    fl = flat(losses)
+    assert set('loss0/' + k for k in fl) == set(k for k in z.files if k.startswith('loss0/'))
+    for k, v in fl.items():
+        assert abs(v - float(z['loss0/' + k])) < 2e-5, k
+    losses['total'].backward()
+    for n, p in model.named_parameters():
+        ref = z['g0/' + n]
+        got = p.grad.cpu().numpy()
+        if np.linalg.norm(ref) < 1e-12:
+            assert np.abs(got).max() < 1e-6, n
+        else:
+            assert rel(got, ref) < 5e-4, n
+    clip1 = to_dev(synth_clip(1, C, R, T, unp, density=float(z['density'])))
+    _, losses1 = reference_call(model, clip1)
+    assert abs(float(losses1['total']) - float(z['loss1/total'])) < 2e-5
+    losses1['total'].backward()                 # accumulates (sum) into the same p.grad
+    opt.step()
+    for n, p in model.named_parameters():
+        assert np.abs(p.detach().cpu().numpy() - z['p1/' + n]).max() < 3e-4, n
+
+
+def test_stage_methods_compose_to_forward_and_backprop():
+    z, model = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    clip = to_dev(synth_clip(0, C, R, T, True, density=float(z['density'])))
+    style, melody, rhythm = model.extract_style(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'],
+                                                clip['unpitched'])
+    assert rel(style.detach().cpu(), z['mid/style_encoder/0']) < 1e-4
+    assert rel(melody.detach().cpu(), z['mid/melody_encoder/0']) < 1e-4
+    ip, mp, bp = model.predict_song_info(style, rhythm)
+    xp, xu = model.apply_style(style, melody, rhythm, clip['instruments_features'], unpitched=True)
+    assert rel(xp.detach().cpu(), z['out/pitched']) < 1e-4 and rel(xu.detach().cpu(), z['out/unpitched']) < 1e-4
+    import style.model as m
+    losses = m.get_total_loss(ip, clip['used_instruments'], bp, clip['bpm_int'], mp, clip['mode'], xp, clip['pitched'],
+                              xu, clip['unpitched'], normalize=True)
+    losses['total'].backward()
+    for n, p in model.named_parameters():
+        ref = z['g0/' + n]
+        if np.linalg.norm(ref) > 1e-12:
+            assert rel(p.grad.cpu().numpy(), ref) < 5e-4, n
+    with torch.no_grad():      # inference use (style_transfer.py:67-74,101-131)
+        s2, m2, r2 = model.extract_style(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], None)
+        xp2, xu2 = model.apply_style(s2, m2, r2, clip['instruments_features'][:, :1], unpitched=False)
+    assert xu2 is None and xp2.shape == (1, 1, R, T, 10, 56, 5) and not xp2.requires_grad
+
+
+def test_differentiating_another_loss_leaf():
+    z, model = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    clipc = synth_clip(0, C, R, T, True, density=float(z['density']))
+    clip = to_dev(clipc)
+    _, losses = reference_call(model, clip)
+    losses['channels_loss']['pitched']['velocity_loss'].backward()
+    named = {k[3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith('p0/')}
+    info, xp, xu = so.forward(named, clipc['mode'], clipc['bpm'], clipc['pitched'], clipc['instruments_features'], clipc['unpitched'])
+    ref = so.total_loss(info[0], clipc['used_instruments'], info[2], clipc['bpm_int'], info[1], clipc['mode'], xp,
+                        clipc['pitched'], xu, clipc['unpitched'])
+    ref['channels_loss_pitched_velocity_loss'].backward()
+    n = 'pitched_style_applier.linear.weight'
+    assert rel(dict(model.named_parameters())[n].grad.cpu().numpy(), named[n].grad.numpy()) < 5e-4
+
+
+def test_full_width_seed108_model():
+    z = np.load(os.path.join(GOLDEN, 'full_seed108.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    model = build_model(FULL, seed=108).to(DEV)
+    clip = to_dev(synth_clip(3, C, R, T, True))
+    (ip, mp, bp, xp, xu), losses = reference_call(model, clip)
+    assert rel(ip.detach().cpu(), z['out/instruments']) < 1e-4 and rel(bp.detach().cpu(), z['out/bpm']) < 1e-4
+    assert rel(xp.detach().cpu()[0, 1, 1, 2], z['slice/pitched']) < 1e-4
+    assert rel(xu.detach().cpu()[0, 0, 1, 2], z['slice/unpitched']) < 1e-4
+    for k, v in flat(losses).items():
+        assert abs(v - float(z['loss0/' + k])) < 2e-5, k
+    losses['total'].backward()
+    for n, p in model.named_parameters():
+        g = p.grad.double().reshape(-1).cpu()
+        ref = z['gf/' + n]                          # [sum, abs-sum, sq-sum, first, last] from the reference
+        if ref[1] < 1e-9:
+            continue
+        assert abs(float(g.abs().sum()) - ref[1]) < 5e-4 * ref[1] + 1e-9, n
+        assert abs(float((g * g).sum()) - ref[2]) < 1e-3 * ref[2] + 1e-12, n
+
+
+def test_trajectory_six_iterations_three_adam_steps():
+    """train-model.py loop on the bench clip shape with seed-108 weights: loss leaves of every iteration
+    against the reference's own run (tests/golden/trajectory_seed108.npz)."""
+    from style.optim import FusedAdam
+    z = np.load(os.path.join(GOLDEN, 'trajectory_seed108.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    keys = [str(k) for k in z['loss_keys']]
+    model = build_model(FULL, seed=108).to(DEV)
+    opt = FusedAdam(model)
+    for it in range(6):
+        clip = to_dev(synth_clip(it, C, R, T, True))
+        _, losses = reference_call(model, clip)
+        losses['total'].backward()
+        fl = flat(losses)
+        for j, k in enumerate(keys):
+            assert abs(fl[k] - z['losses'][it, j]) < 3e-4, (it, k, fl[k], z['losses'][it, j])
+        if (it + 1) % 2 == 0:
+            opt.step()
+    for n, p in model.named_parameters():
+        x = p.detach().double().reshape(-1).cpu()
+        ref = z['pf/' + n]
+        assert abs(float(x.abs().sum()) - ref[1]) < 2e-3 * ref[1] + 1e-6, n
+
+
+def test_hard_output_matches_oracle_and_mutates_input():
+    import style.model as m
+    x = torch.rand(1, 2, 2, 3, 10, 56, 5)
+    x[..., 1] *= (torch.rand(x.shape[:-1]) < .5) * 0.03 + (torch.rand(x.shape[:-1]) < .3)
+    ref = so.hard_output(x.clone())
+    xd = x.to(DEV)
+    out = m.hard_output(xd)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(xd[..., 1].cpu(), ref[..., 1])       # velocities zeroed in place, like the reference
+    xu = torch.rand(1, 1, 2, 3, 10, 47, 2)
+    assert torch.equal(m.hard_output(xu.to(DEV)).cpu(), so.hard_output(xu.clone()))
