@@ -59,6 +59,8 @@ def init_params(native, dims, seed=108):
 def cpu_baseline(flat, table, clip, seconds):
     """The oracle (torch-CPU port of the reference's path, pinned to its fixtures) on this host."""
     from oracle import style_oracle as so
+    # a 1-GPU box owns 16 host cores; torch's default (all 128 visible cores) oversubscribes badly
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     named = {n: flat[o:o + int(np.prod(s))].view(*s).clone().requires_grad_(True) for n, o, s in table}
     opt = so.Adam(named.values())
     so.iteration(named, clip, fast=True)          # warm

@@ -61,6 +61,7 @@ _SIGS = {
                                   C.c_int32, C.c_double, C.c_int32, _P]),
     'mst_hard_output': (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P]),
     'mst_plan_step_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    'mst_plan_step_info': (C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
     'mst_plan_time_steps': (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     'mst_version': (C.c_char_p, []),
 }
