@@ -4,18 +4,26 @@
 //   dx_c = g n_c / S + ((a_c - b) / S) x_c / n_c,  a_c = sum(g x_c),  b = sum(g out),  S = sum_c n_c.
 // Both directions are a global reduction followed by an elementwise pass, so each is two
 // launches; partial sums are written per workgroup and re-summed in index order by every
-// consumer workgroup (deterministic, no float atomics).  HBM-bound: x is read twice per
-// direction, coalesced along the feature axis.
+// consumer workgroup (deterministic, no float atomics).  blockIdx.y selects the call site, so
+// independent sites of one dependency level share launches.  HBM/L2-bound: x is read twice per
+// direction, coalesced along the feature axis; the backward reduce reads g once for all channels.
 #include "mst_common.h"
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// sums `nv` per-lane values across the 256-lane workgroup; result for value v lands in red[v]
+__device__ __forceinline__ void block_sum_multi(float* vals, int nv, float (*part)[COMBINE_MAXC + 1], float* red) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v <= COMBINE_MAXC; ++v) {       // static indices keep vals[] in registers; nv is workgroup-uniform
+        if (v < nv) {
+            float x = vals[v];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0) part[wv][v] = x;
+        }
+    }
     __syncthreads();
-    if (lane == 0) red[wv] = v;
+    if ((int)threadIdx.x < nv) red[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __device__ __forceinline__ int64_t elem_off(const CombineDesc& d, int64_t e) {
@@ -23,33 +31,45 @@ __device__ __forceinline__ int64_t elem_off(const CombineDesc& d, int64_t e) {
     return r * d.ld + (e - r * d.cols);
 }
 
-// grid (nblk, Cn): part[c*MAXBLK + blk] = partial sum of squares of slice c
-__global__ __launch_bounds__(256) void combine_sumsq_kernel(const CombineDesc* __restrict__ dp, Bases b) {
-    const CombineDesc& d = *dp;
-    __shared__ float red[4];
-    const int c = blockIdx.y;
-    const float* x = b.p[SP_WS] + d.x_off + (int64_t)c * d.cs;
+// part[blk*(MAXC+1) + c] = partial sum of squares of slice c over this workgroup's elements
+__global__ __launch_bounds__(256) void combine_sumsq_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc& d = descs[blockIdx.y];
+    if ((int)blockIdx.x >= d.nblk) return;
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    __shared__ float red[COMBINE_MAXC + 1];
+    const float* x = b.p[SP_WS] + d.x_off;
     const int64_t n = (int64_t)d.rows * d.cols;
-    float acc = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        float v = x[elem_off(d, e)];
-        acc = fmaf(v, v, acc);
+    float acc[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+        const int64_t eo = elem_off(d, e);
+#pragma unroll
+        for (int c = 0; c < COMBINE_MAXC; ++c) {
+            if (c < d.Cn) { const float v = x[(int64_t)c * d.cs + eo]; acc[c] = fmaf(v, v, acc[c]); }
+        }
     }
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) b.p[SP_TMP][d.part_off + c * COMBINE_MAXBLK + blockIdx.x] = acc;
+    block_sum_multi(acc, d.Cn, part, red);
+    if ((int)threadIdx.x < d.Cn) b.p[SP_TMP][d.part_off + blockIdx.x * (COMBINE_MAXC + 1) + threadIdx.x] = red[threadIdx.x];
 }
 
-// grid (nblk): norms from the partials, then out = sum_c x_c n_c / S
-__global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* __restrict__ dp, Bases b) {
-    const CombineDesc& d = *dp;
+// norms from the partials, then out = sum_c x_c n_c / S
+__global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc& d = descs[blockIdx.y];
+    if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float nrm[COMBINE_MAXC + 1];
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    __shared__ float red[COMBINE_MAXC + 1];
     float* ws = b.p[SP_WS];
     float* tmp = b.p[SP_TMP];
-    if (threadIdx.x < d.Cn) {
-        float s = 0.f;
-        for (int k = 0; k < d.nblk; ++k) s += tmp[d.part_off + threadIdx.x * COMBINE_MAXBLK + k];
-        nrm[threadIdx.x] = sqrtf(1.f + s);
+    {   // re-sum the per-workgroup partials: lane k takes partial k, then a fixed-order tree (nblk <= 256)
+        float vals[COMBINE_MAXC + 1];
+#pragma unroll
+        for (int c = 0; c <= COMBINE_MAXC; ++c)
+            vals[c] = (c < d.Cn && (int)threadIdx.x < d.nblk) ? tmp[d.part_off + threadIdx.x * (COMBINE_MAXC + 1) + c] : 0.f;
+        block_sum_multi(vals, d.Cn, part, red);
     }
+    if ((int)threadIdx.x < d.Cn) nrm[threadIdx.x] = sqrtf(1.f + red[threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
         float S = 0.f;
@@ -57,11 +77,11 @@ __global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* _
         nrm[COMBINE_MAXC] = S;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x <= d.Cn)
-        tmp[d.stats_off + threadIdx.x] = threadIdx.x < d.Cn ? nrm[threadIdx.x] : nrm[COMBINE_MAXC];
+    if (blockIdx.x == 0 && (int)threadIdx.x <= d.Cn)
+        tmp[d.stats_off + threadIdx.x] = (int)threadIdx.x < d.Cn ? nrm[threadIdx.x] : nrm[COMBINE_MAXC];
     const float S = nrm[COMBINE_MAXC];
     const int64_t n = (int64_t)d.rows * d.cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         float acc = 0.f;
         for (int c = 0; c < d.Cn; ++c) acc += ws[d.x_off + (int64_t)c * d.cs + eo] * nrm[c];
@@ -69,59 +89,80 @@ __global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* _
     }
 }
 
-// grid (nblk): part[blk*(Cn+1) + c] = partial a_c, part[blk*(Cn+1) + Cn] = partial b
-__global__ __launch_bounds__(256) void combine_bwd_reduce_kernel(const CombineDesc* __restrict__ dp, Bases b) {
-    const CombineDesc& d = *dp;
-    __shared__ float red[4];
-    float* ws = b.p[SP_WS];
+// part[blk*(MAXC+1) + c] = partial a_c, part[blk*(MAXC+1) + Cn] = partial b
+__global__ __launch_bounds__(256) void combine_bwd_reduce_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc& d = descs[blockIdx.y];
+    if ((int)blockIdx.x >= d.nblk) return;
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    __shared__ float red[COMBINE_MAXC + 1];
+    const float* ws = b.p[SP_WS];
     const float* gr = b.p[SP_GRAD];
     const int64_t n = (int64_t)d.rows * d.cols;
-    for (int c = 0; c <= d.Cn; ++c) {
-        float acc = 0.f;
-        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-            float g = gr[d.gout_off + e];
-            float v = c < d.Cn ? ws[d.x_off + (int64_t)c * d.cs + elem_off(d, e)] : ws[d.out_off + e];
-            acc = fmaf(g, v, acc);
+    float acc[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+        const int64_t eo = elem_off(d, e);
+        const float g = gr[d.gout_off + e];
+#pragma unroll
+        for (int c = 0; c < COMBINE_MAXC; ++c) {
+            if (c < d.Cn) acc[c] = fmaf(g, ws[d.x_off + (int64_t)c * d.cs + eo], acc[c]);
         }
-        acc = block_sum(acc, red);
-        if (threadIdx.x == 0) b.p[SP_TMP][d.part_off + blockIdx.x * (COMBINE_MAXC + 1) + c] = acc;
+        acc[COMBINE_MAXC] = fmaf(g, ws[d.out_off + e], acc[COMBINE_MAXC]);
     }
+    // move b next to the a_c so one multi-value reduction covers all Cn+1 sums
+    float vals[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c < COMBINE_MAXC; ++c) vals[c] = acc[c];
+    vals[COMBINE_MAXC] = 0.f;
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) if (c == d.Cn) vals[c] = acc[COMBINE_MAXC];
+    block_sum_multi(vals, d.Cn + 1, part, red);
+    if ((int)threadIdx.x <= d.Cn) b.p[SP_TMP][d.part_off + blockIdx.x * (COMBINE_MAXC + 1) + threadIdx.x] = red[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDesc* __restrict__ dp, Bases b) {
-    const CombineDesc& d = *dp;
+__global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc& d = descs[blockIdx.y];
+    if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float coef[COMBINE_MAXC + 1];
-    float* ws = b.p[SP_WS];
+    __shared__ float nc_s[COMBINE_MAXC + 1];
+    const float* ws = b.p[SP_WS];
     float* gr = b.p[SP_GRAD];
     const float* tmp = b.p[SP_TMP];
-    if (threadIdx.x <= d.Cn) {
-        float s = 0.f;
-        for (int k = 0; k < d.nblk; ++k) s += tmp[d.part_off + k * (COMBINE_MAXC + 1) + threadIdx.x];
-        coef[threadIdx.x] = s;
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    {
+        float vals[COMBINE_MAXC + 1];
+#pragma unroll
+        for (int c = 0; c <= COMBINE_MAXC; ++c)
+            vals[c] = (c <= d.Cn && (int)threadIdx.x < d.nblk) ? tmp[d.part_off + threadIdx.x * (COMBINE_MAXC + 1) + c] : 0.f;
+        block_sum_multi(vals, d.Cn + 1, part, coef);
     }
+    if ((int)threadIdx.x <= d.Cn) nc_s[threadIdx.x] = tmp[d.stats_off + threadIdx.x];       // n_c ..., S
     __syncthreads();
-    const float S = tmp[d.stats_off + d.Cn];
+    const float S = nc_s[d.Cn];
     const float bsum = coef[d.Cn];
     const int64_t n = (int64_t)d.rows * d.cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         const float g = gr[d.gout_off + e];
         for (int c = 0; c < d.Cn; ++c) {
-            const float nc = tmp[d.stats_off + c];
+            const float nc = nc_s[c];
             const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
             gr[d.gx_off + (int64_t)c * d.cs + eo] += g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
         }
     }
 }
 
-int launch_combine_fwd(const CombineDesc* dev, const CombineDesc& h, Bases b, hipStream_t s) {
-    hipLaunchKernelGGL(combine_sumsq_kernel, dim3(h.nblk, h.Cn), dim3(256), 0, s, dev, b);
-    hipLaunchKernelGGL(combine_apply_kernel, dim3(h.nblk), dim3(256), 0, s, dev, b);
+int launch_combine_fwd(const CombineDesc* dev, int count, int max_nblk, Bases b, hipStream_t s) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(combine_sumsq_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
+    hipLaunchKernelGGL(combine_apply_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();
 }
 
-int launch_combine_bwd(const CombineDesc* dev, const CombineDesc& h, Bases b, hipStream_t s) {
-    hipLaunchKernelGGL(combine_bwd_reduce_kernel, dim3(h.nblk), dim3(256), 0, s, dev, b);
-    hipLaunchKernelGGL(combine_bwd_apply_kernel, dim3(h.nblk), dim3(256), 0, s, dev, b);
+int launch_combine_bwd(const CombineDesc* dev, int count, int max_nblk, Bases b, hipStream_t s) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(combine_bwd_reduce_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
+    hipLaunchKernelGGL(combine_bwd_apply_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();
 }

@@ -8,8 +8,8 @@
 // the source tensors — and bias/activation (or the activation derivative on the backward
 // side) are fused into the tile load / epilogue.
 //
-// Tiling: 32x32 outputs x 128-deep k-tile per 256-thread workgroup; the four waves split the
-// k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
+// Tiling: 32x32 outputs x KD-deep k-tile (KD = 32 / 64 / 128 by the descriptor's k range) per
+// 256-thread workgroup; the four waves split the k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
 // float4 fragment reads).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
 // tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
 // Independent GEMMs share one launch: the 1-D grid is the concatenation of every member's
@@ -95,7 +95,7 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
     }
 }
 
-template <int AK, int BKIND, int OK, int AKF, int BKF>
+template <int AK, int BKIND, int OK, int AKF, int BKF, int KD>
 __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
                                           float (*As)[GEMM_BM + 4], float (*Bs)[GEMM_BN + 4]) {
     // 32x32 output tile per workgroup, 128-deep k-tile: wave w owns k rows [32w, 32w+32) of the
@@ -110,8 +110,10 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     const gcptr baseA2 = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
     const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // KD = depth of the k-tile staged per step (32 / 64 / 128, chosen per descriptor from its k range):
+    // shallow reductions (K = 8..64 is common here) do not pay for a 128-deep tile
     int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
-    kchunk = (kchunk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    kchunk = (kchunk + KD - 1) / KD * KD;
     const int k0 = split * kchunk;
     const int k1 = min(d.K, k0 + kchunk);
     const int wv = tid >> 6, lane = tid & 63;
@@ -125,15 +127,16 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-    constexpr int NL = GEMM_BM * GEMM_BK / 256;      // tile elements per lane and operand (16)
+    constexpr int NL = GEMM_BM * KD / 256;           // tile elements per lane and operand (4 / 8 / 16)
+    constexpr int KW = KD / 4;                       // k rows of the tile each wave reduces
     float va[NL], ya[NL], vb[NL];
 
-    // element e = tid + 256*i of the 32 x 128 tile: (row, k) = (e / 128, e % 128) when lanes walk k,
+    // element e = tid + 256*i of the 32 x KD tile: (row, k) = (e / KD, e % KD) when lanes walk k,
     // (e % 32, e / 32) when lanes walk the row index
-#define A_ROW(i) (AKF ? (tid >> 7) + 2 * (i) : (tid & 31))
-#define A_KL(i) (AKF ? (tid & 127) : (tid >> 5) + 8 * (i))
-#define B_ROW(i) (BKF ? (tid >> 7) + 2 * (i) : (tid & 31))
-#define B_KL(i) (BKF ? (tid & 127) : (tid >> 5) + 8 * (i))
+#define A_ROW(i) (AKF ? (tid / KD) + (256 / KD) * (i) : (tid & 31))
+#define A_KL(i) (AKF ? (tid % KD) : (tid >> 5) + 8 * (i))
+#define B_ROW(i) (BKF ? (tid / KD) + (256 / KD) * (i) : (tid & 31))
+#define B_KL(i) (BKF ? (tid % KD) : (tid >> 5) + 8 * (i))
 #define GEMM_ISSUE(KT)                                                                                     \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
@@ -159,17 +162,17 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     }
 
     if (k0 < k1) GEMM_ISSUE(k0)
-    for (int kt = k0; kt < k1; kt += GEMM_BK) {
+    for (int kt = k0; kt < k1; kt += KD) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             As[A_KL(i)][A_ROW(i)] = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? va[i] * ya[i] : va[i];
             Bs[B_KL(i)][B_ROW(i)] = vb[i];
         }
         __syncthreads();
-        if (kt + GEMM_BK < k1) GEMM_ISSUE(kt + GEMM_BK)      // next tile's loads fly under this tile's FMAs
+        if (kt + KD < k1) GEMM_ISSUE(kt + KD)                // next tile's loads fly under this tile's FMAs
 #pragma unroll
-        for (int kk = 0; kk < GEMM_KW; ++kk) {
-            const int k = wv * GEMM_KW + kk;
+        for (int kk = 0; kk < KW; ++kk) {
+            const int k = wv * KW + kk;
             float a[4], bb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; bb[i] = Bs[k][tx * 4 + i]; }
@@ -217,17 +220,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
     const int local = blockIdx.x - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
     const int tile = local % ntile, split = local / ntile;
-    switch (d.variant) {
-    case GV_LIN_FWD: gemm_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_FWD_PERM: gemm_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DW: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DW_PERM: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DA: gemm_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, tile, split, As, Bs); break;
-    case GV_CONV_FWD: gemm_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_CONV_DW: gemm_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs); break;
-    case GV_HH_DW: gemm_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+#define GEMM_CASE(V, A_, B_, O_, AF_, BF_)                                                          \
+    case (V) * 3 + 0: gemm_body<A_, B_, O_, AF_, BF_, 32>(d, b, tile, split, As, Bs); break;           \
+    case (V) * 3 + 1: gemm_body<A_, B_, O_, AF_, BF_, 64>(d, b, tile, split, As, Bs); break;           \
+    case (V) * 3 + 2: gemm_body<A_, B_, O_, AF_, BF_, 128>(d, b, tile, split, As, Bs); break;
+    switch (d.variant * 3 + d.kdsel) {
+        GEMM_CASE(GV_LIN_FWD, OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1)
+        GEMM_CASE(GV_LIN_FWD_PERM, OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1)
+        GEMM_CASE(GV_LIN_DW, OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0)
+        GEMM_CASE(GV_LIN_DW_PERM, OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0)
+        GEMM_CASE(GV_LIN_DA, OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0)
+        GEMM_CASE(GV_CONV_FWD, OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1)
+        GEMM_CASE(GV_CONV_DW, OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0)
+        GEMM_CASE(GV_HH_DW, OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0)
     default: break;
     }
+#undef GEMM_CASE
 }
 
 int gemm_variant(const GemmDesc& g) {

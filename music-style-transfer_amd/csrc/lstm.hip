@@ -33,7 +33,10 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
     float w[REG ? 64 : 1];
     if (REG && tid < G) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) w[k] = k < H ? whh[(int64_t)tid * H + k] : 0.f;
+        for (int k = 0; k < 64; ++k) {       // unconditional (clamped) loads: all 64 in flight, no branches
+            const float v = whh[(int64_t)tid * H + min(k, H - 1)];
+            w[k] = k < H ? v : 0.f;
+        }
     }
     float bias[4] = {0.f, 0.f, 0.f, 0.f}, zq[4] = {0.f, 0.f, 0.f, 0.f};
     const int s0 = d.reverse ? d.S - 1 : 0;
@@ -58,10 +61,13 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
         MST_LDS_BARRIER();
         if (REG) {
             if (tid < G) {
-                float z = 0.f;
+                float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;       // 4 independent FMA chains
 #pragma unroll
-                for (int k = 0; k < 64; ++k) z = fmaf(w[k], h_s[k], z);
-                z_s[tid] = z;
+                for (int k = 0; k < 64; k += 4) {
+                    z0 = fmaf(w[k], h_s[k], z0); z1 = fmaf(w[k + 1], h_s[k + 1], z1);
+                    z2 = fmaf(w[k + 2], h_s[k + 2], z2); z3 = fmaf(w[k + 3], h_s[k + 3], z3);
+                }
+                z_s[tid] = (z0 + z1) + (z2 + z3);
             }
         } else if (tid < G) {
             // thread per gate row over the transposed copy: lane-contiguous (coalesced) reads, 4 chains
@@ -101,9 +107,8 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
     const int bi = blockIdx.x;
     if (bi >= d.B) return;
     const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
-    __shared__ float dh_next[256];
     __shared__ float dz_s[1024];
-    __shared__ float red_s[1024];
+    __shared__ float red_s[1024];      // four partial sums of dh_{t-1} per hidden unit, consumed by the next step
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* tmp = b.p[SP_TMP];
     float* gr = b.p[SP_GRAD];
@@ -111,9 +116,12 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
     float w[REG ? 64 : 1];
     if (REG && tid < G) {
 #pragma unroll
-        for (int jj = 0; jj < 64; ++jj) w[jj] = jj < H ? whh[((int64_t)part * H + jj) * H + kk] : 0.f;
+        for (int jj = 0; jj < 64; ++jj) {
+            const float v = whh[((int64_t)part * H + min(jj, H - 1)) * H + kk];
+            w[jj] = jj < H ? v : 0.f;
+        }
     }
-    if (tid < 256) dh_next[tid] = 0.f;
+    red_s[tid] = 0.f;
     float dc_next = 0.f;
     // streamed operands of a step (saved gates, cell states, incoming gradient), prefetched one step ahead
     float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
         if (tid < H) {
             if (step > 0) LSTM_LOAD(step - 1, nx)
             const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], c = sv[4], cprev = sv[5];
-            const float dh = sv[6] + dh_next[tid];
+            const float dh = sv[6] + ((red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]));
             const float tc = tanhf(c);
             const float dc = dc_next + dh * og * (1.f - tc * tc);
             const float dzi = dc * gg * ig * (1.f - ig);
@@ -150,11 +158,19 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
             gz[tid] = dzi; gz[H + tid] = dzf; gz[2 * H + tid] = dzg; gz[3 * H + tid] = dzo;
         }
         MST_LDS_BARRIER();
-        if (tid < G) {   // dh_{t-1}[k] = sum_j W_hh[j,k] dz[j], four partial sums per k
-            float acc = 0.f;
+        float acc = 0.f;
+        if (tid < G) {   // dh_{t-1}[k] = sum_j W_hh[j,k] dz[j], four partial sums per k (summed by the next step)
             if (REG) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const int base = part * H;
 #pragma unroll
-                for (int jj = 0; jj < 64; ++jj) acc = fmaf(w[jj], dz_s[min(part * H + jj, G - 1)], acc);
+                for (int jj = 0; jj < 64; jj += 4) {
+                    a0 = fmaf(w[jj], dz_s[min(base + jj, G - 1)], a0);
+                    a1 = fmaf(w[jj + 1], dz_s[min(base + jj + 1, G - 1)], a1);
+                    a2 = fmaf(w[jj + 2], dz_s[min(base + jj + 2, G - 1)], a2);
+                    a3 = fmaf(w[jj + 3], dz_s[min(base + jj + 3, G - 1)], a3);
+                }
+                acc = (a0 + a1) + (a2 + a3);
             } else {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const float* wc = whh + (int64_t)part * H * H + kk;      // coalesced along kk
@@ -169,14 +185,12 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
                 for (; jj < H; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
                 acc = (a0 + a1) + (a2 + a3);
             }
-            red_s[tid] = acc;
         }
-        MST_LDS_BARRIER();
         if (tid < H) {
-            dh_next[tid] = (red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]);
 #pragma unroll
             for (int q = 0; q < 7; ++q) sv[q] = nx[q];     // the prefetch landed under the matvec above
         }
+        if (tid < G) red_s[tid] = acc;                    // phase A's reads of red_s ended before the barrier above
         MST_LDS_BARRIER();
     }
 #undef LSTM_LOAD

@@ -75,6 +75,7 @@ struct GemmDesc {
     int32_t M, N, K, ksplit;
     int32_t variant;     // GV_* instantiation (filled by the plan from the operand kinds)
     int32_t blk_begin;   // first workgroup of this member inside its (merged) launch
+    int32_t kdsel;       // k-tile depth: 0 -> 32, 1 -> 64, 2 -> 128
     Operand A, B;
     OutSpec out;
 };
@@ -113,7 +114,7 @@ struct LstmDesc {
 
 // ---- combine (style/model.py:796-815): out = sum_c x_c n_c / sum_c n_c
 #define COMBINE_MAXC 32
-#define COMBINE_MAXBLK 64
+#define COMBINE_MAXBLK 256
 struct CombineDesc {
     int32_t Cn, rows, cols, ld;  // each slice: rows x cols, row stride ld
     int64_t x_off, cs;           // slice c at x_off + c*cs                [SP_WS]
@@ -168,8 +169,8 @@ int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int st
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
-int launch_combine_fwd(const CombineDesc* dev_desc, const CombineDesc& host, Bases b, hipStream_t s);
-int launch_combine_bwd(const CombineDesc* dev_desc, const CombineDesc& host, Bases b, hipStream_t s);
+int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
+int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
 int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
 int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);

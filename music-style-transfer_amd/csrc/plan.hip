@@ -7,6 +7,7 @@
 // Workspace layout (floats):  [ activations | gradients (same offsets) | scratch ]
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -200,6 +201,7 @@ struct mst_plan {
     // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
     std::vector<Step> sched[2];
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
+    std::vector<CombineDesc> s_combines;
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
@@ -429,8 +431,8 @@ struct mst_plan {
         int64_t nb = ((int64_t)rows * cols + 1023) / 1024;
         c.nblk = (int)(nb < 1 ? 1 : (nb > COMBINE_MAXBLK ? COMBINE_MAXBLK : nb));
         Op op; op.stage = stage;
-        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, 0, 0});
-        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, 0, 0});
+        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, c.nblk, 0});
+        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, c.nblk, 0});
         combines.push_back(c);
         ops.push_back(op);
     }
@@ -790,13 +792,15 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
         for (int i = 0; i < n; ++i) {
             if (done[i] || level[i] != lv) continue;
             const Step& s0 = seq[i];
-            const bool mergeable = s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
-                                   s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
+            static const bool no_merge = getenv("MST_NO_MERGE") != nullptr;      // profiling aid: one launch per member
+            const bool mergeable = !no_merge && (s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
+                                   s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
             Step m = s0; m.count = 0;
             if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
             else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
             else if (s0.kind == K_SEGRED) m.first = (int)s_segreds.size();
             else if (s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B) m.first = (int)s_lstms.size();
+            else if (s0.kind == K_COMB_F || s0.kind == K_COMB_B) m.first = (int)s_combines.size();
             for (int j = i; j < n; ++j) {
                 if (done[j] || level[j] != lv) continue;
                 const Step& s = seq[j];
@@ -806,10 +810,12 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 if (j != i && !mergeable) continue;
                 done[j] = 1;
                 for (int q = 0; q < s.count; ++q) {
-                    if (s.kind == K_GEMM) { GemmDesc g = gemms[s.first + q]; g.variant = gemm_variant(g); if (g.variant < 0) err = MST_ERR_UNSUPPORTED; s_gemms.push_back(g); }
+                    if (s.kind == K_GEMM) { GemmDesc g = gemms[s.first + q]; g.variant = gemm_variant(g);
+                        { const int kr = (g.K + g.ksplit - 1) / g.ksplit; g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2); } if (g.variant < 0) err = MST_ERR_UNSUPPORTED; s_gemms.push_back(g); }
                     else if (s.kind == K_GATHER) s_gathers.push_back(gathers[s.first + q]);
                     else if (s.kind == K_SEGRED) s_segreds.push_back(segreds[s.first + q]);
                     else if (s.kind == K_LSTM_T || s.kind == K_LSTM_F || s.kind == K_LSTM_B) s_lstms.push_back(lstms[s.first + q]);
+                    else if (s.kind == K_COMB_F || s.kind == K_COMB_B) s_combines.push_back(combines[s.first + q]);
                 }
                 m.count += s.count;
                 if (s.a > m.a) m.a = s.a;
@@ -849,7 +855,7 @@ static int up(const std::vector<D>& v, D** dev) {
 int mst_plan::upload() {
     int e = 0;
     e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
-    e |= up(combines, &d_combines); e |= up(notes, &d_notes);
+    e |= up(s_combines, &d_combines); e |= up(notes, &d_notes);
     for (int s = 0; s < 3; ++s) {
         e |= up(slabs[s], &d_slabs[s]);
         for (size_t i = 0; i < slabs[s].size(); ++i)
@@ -921,8 +927,8 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
     case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
-    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, p->combines[s.first], b, st);
-    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, p->combines[s.first], b, st);
+    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, b, st);
+    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, b, st);
     case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
     case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->notes[s.first], b, st);
     case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
@@ -946,11 +952,15 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
 
 extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
     if (!p || !ws) return MST_ERR_ARG;
-    for (int s = 0; s < 3; ++s) {
-        if (!((mask >> s) & 1)) continue;
-        const int64_t n = p->stage_end[s] - p->stage_begin[s];
+    // the stage regions are allocated back to back: clear runs of selected stages with one memset each
+    for (int s = 0; s < 3;) {
+        if (!((mask >> s) & 1)) { ++s; continue; }
+        int e = s;
+        while (e + 1 < 3 && ((mask >> (e + 1)) & 1) && p->stage_begin[e + 1] == p->stage_end[e]) ++e;
+        const int64_t n = p->stage_end[e] - p->stage_begin[s];
         if (n > 0 && hipMemsetAsync(ws + p->act_top + p->stage_begin[s], 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return MST_ERR_LAUNCH;
+        s = e + 1;
     }
     return MST_OK;
 }
@@ -1042,7 +1052,7 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
         }
         break;
     case K_COMB_F: case K_COMB_B: {
-        const CombineDesc& c = p->combines[s.first];
+        const CombineDesc& c = p->s_combines[s.first];
         const double n = (double)c.rows * c.cols;
         f = n * c.Cn * (s.kind == K_COMB_F ? 4.0 : 8.0);
         b = 4.0 * n * (s.kind == K_COMB_F ? 2.0 * c.Cn + 1 : 4.0 * c.Cn + 2);
@@ -1090,7 +1100,7 @@ extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t b
         else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
         else if (s->kind == K_GATHER) { const GatherDesc& g = p->s_gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
         else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->s_segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
-        else if (s->kind == K_COMB_F || s->kind == K_COMB_B) { const CombineDesc& c = p->combines[s->first]; o[0] = c.Cn; o[1] = c.rows; o[2] = c.cols; o[3] = c.nblk; }
+        else if (s->kind == K_COMB_F || s->kind == K_COMB_B) { const CombineDesc& c = p->s_combines[s->first]; o[0] = c.Cn; o[1] = c.rows; o[2] = c.cols; o[3] = c.nblk; }
     }
     return idx;
 }
