@@ -80,6 +80,17 @@ def cpu_baseline(flat, table, clip, seconds):
                        f'mkldnn LSTM), {dt:.1f} s')
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/), or None.
+    bench.py cannot run the profiler on itself; the counters are collected by the command recorded in the file."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        d = json.load(open(path))
+        return d[kernel]['hbm_bytes_per_launch'] if kernel in d else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -89,6 +100,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel time table to stderr')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only to rehearse N>1 on one GPU')
+    ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -97,13 +110,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', 0 if args.share_device else local)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from oracle.synth import synth_clip
     from style import _native as nat
@@ -187,7 +203,7 @@ def main():
             achieved = fl / (ms * 1e-3) / 1e12
             roof = dict(bound='mfma', kernel=KIND_NAMES[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
                         flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / PEAK_F32_TFLOPS, traffic=None,
+                        frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(KIND_NAMES[kind]),
                         whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
                                              achieved_tflops=algorithmic_flops_per_iter(**CLIP) / (dt / args.steps) / 1e12))
             if args.breakdown:
