@@ -11,7 +11,8 @@
 // is LDS-only (MST_LDS_BARRIER), so streamed stores / prefetches never stall a step.
 #include "mst_common.h"
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return __fdividef(1.f, 1.f + MST_FAST_EXP(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.f * sigm(2.f * x) - 1.f; }
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -86,10 +87,12 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
         MST_LDS_BARRIER();
         if (tid < H) {
             const float ig = sigm(z_s[tid] + zq[0] + bias[0]), fg = sigm(z_s[H + tid] + zq[1] + bias[1]);
-            const float gg = tanhf(z_s[2 * H + tid] + zq[2] + bias[2]), og = sigm(z_s[3 * H + tid] + zq[3] + bias[3]);
+            const float gg = tanh_fast(z_s[2 * H + tid] + zq[2] + bias[2]), og = sigm(z_s[3 * H + tid] + zq[3] + bias[3]);
             tmp[d.hprev_off + row * H + tid] = h_s[tid];
             c = fg * c + ig * gg;
-            const float h = og * tanhf(c);
+            const float tc = tanh_fast(c);
+            const float h = og * tc;
+            tmp[d.tc_off + row * H + tid] = tc;
             float* g = tmp + d.gates_off + row * G;
             g[tid] = ig; g[H + tid] = fg; g[2 * H + tid] = gg; g[3 * H + tid] = og;
             tmp[d.c_off + row * H + tid] = c;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
         const int64_t row_ = (int64_t)bi * d.S + s_;                                                    \
         const float* g_ = tmp + d.gates_off + row_ * G;                                                 \
         DST[0] = g_[tid]; DST[1] = g_[H + tid]; DST[2] = g_[2 * H + tid]; DST[3] = g_[3 * H + tid];     \
-        DST[4] = tmp[d.c_off + row_ * H + tid];                                                         \
+        DST[4] = tmp[d.tc_off + row_ * H + tid];                                                        \
         DST[5] = (STEP) > 0 ? tmp[d.c_off + ((int64_t)bi * d.S + sp_) * H + tid] : 0.f;                 \
         DST[6] = gr[d.gout_off + row_ * d.out_ld + tid];                                                \
     }
@@ -144,9 +147,8 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
         float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tid < H) {
             if (step > 0) LSTM_LOAD(step - 1, nx)
-            const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], c = sv[4], cprev = sv[5];
+            const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], tc = sv[4], cprev = sv[5];
             const float dh = sv[6] + ((red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]));
-            const float tc = tanhf(c);
             const float dc = dc_next + dh * og * (1.f - tc * tc);
             const float dzi = dc * gg * ig * (1.f - ig);
             const float dzf = dc * cprev * fg * (1.f - fg);

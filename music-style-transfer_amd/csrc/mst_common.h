@@ -14,6 +14,11 @@
 // __syncthreads() it does not drain vmcnt, so global prefetches / streamed stores issued around
 // it stay in flight (on MI355X the vmcnt(0) of __syncthreads() cost ~1-4 us per LSTM step).
 // Only for data exchanged through LDS; the interpreter maps it to its ordinary barrier.
+// hardware exponential (v_exp_f32, ~1 ulp) for the strictly sequential LSTM steps, where the
+// libm-accurate expf/tanhf bodies sit on the critical path; the interpreter maps it to expf
+#ifndef MST_FAST_EXP
+#define MST_FAST_EXP(x) __expf(x)
+#endif
 #ifndef MST_LDS_BARRIER
 #define MST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
@@ -107,6 +112,7 @@ struct LstmDesc {
     int64_t whh_off, bhh_off;                                             // [SP_PAR]
     int64_t out_off; int32_t out_ld;                                      // h written at out_off + row*out_ld
     int64_t gates_off, c_off, hprev_off;                                  // saved (B*S,4H),(B*S,H),(B*S,H)
+    int64_t tc_off;      // saved tanh(c_t) (B*S,H)                         [SP_TMP]
     int64_t gout_off;    // gradient of out (same ld)                      [SP_WS]
     int64_t gzx_off;     // gradient of zx, written (=)
     int64_t whht_off;    // [SP_TMP] W_hh transposed (H x 4H), built per forward when H > 64

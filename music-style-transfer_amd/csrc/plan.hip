@@ -391,7 +391,7 @@ struct mst_plan {
             const int64_t n = (int64_t)sp.B * sp.S;
             LstmDesc l{}; l.B = sp.B; l.S = sp.S; l.H = H; l.reverse = sp.reverse; l.zx_off = zxs[i].off; l.whh_off = whh; l.bhh_off = bhh;
             l.out_off = sp.out.off + sp.coloff; l.out_ld = sp.out.ld;
-            l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H);
+            l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H); l.tc_off = tmp(n * H);
             l.gout_off = sp.out.off + sp.coloff; l.gzx_off = zxs[i].off;
             l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
             lstms.push_back(l);
@@ -715,6 +715,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             acc_add(v, SP_TMP, l.gates_off, n * 4 * l.H, true);
             acc_add(v, SP_TMP, l.c_off, n * l.H, true);
             acc_add(v, SP_TMP, l.hprev_off, n * l.H, true);
+            acc_add(v, SP_TMP, l.tc_off, n * l.H, true);
             if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, false);
             break;
         }
@@ -723,6 +724,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             const int64_t n = (int64_t)l.B * l.S;
             acc_add(v, SP_TMP, l.gates_off, n * 4 * l.H, false);
             acc_add(v, SP_TMP, l.c_off, n * l.H, false);
+            acc_add(v, SP_TMP, l.tc_off, n * l.H, false);
             acc_add(v, SP_GRAD, l.gout_off, (n - 1) * l.out_ld + l.H, false);
             acc_add(v, SP_GRAD, l.gzx_off, n * 4 * l.H, true);
             break;

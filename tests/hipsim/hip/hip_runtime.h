@@ -37,6 +37,7 @@ extern "C" void __sanitizer_finish_switch_fiber(void*, const void**, size_t*);
 #define HIPSIM 1
 #define MST_GLOBAL_AS
 #define MST_LDS_BARRIER() __syncthreads()
+#define MST_FAST_EXP(x) expf(x)
 
 struct dim3 {
     unsigned x, y, z;

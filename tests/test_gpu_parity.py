@@ -37,3 +37,10 @@ def test_oracle_bench_clip(native):
 
 def test_oracle_pitched_only_many_channels(native):
     pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 8, 3, 3, False)
+
+
+def test_oracle_long_clip_config5_shape(native):
+    # BASELINE.json configs[4] on ONE GPU: C=8 channels, R=151 bars (5 min at 120 bpm + 1), T=4 — exercises the
+    # 32-bit index math, the 256-slab weight-gradient splits and long (151-step) LSTM chains at 9.4x the bench clip
+    e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 8, 151, 4, True, clip_id=9)
+    print('long clip: all-gradient rel-L2', e, 'worst tensor', worst)
