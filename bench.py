@@ -138,41 +138,74 @@ def main():
     losses = torch.zeros(nat.N_LOSSES, device=dev)
     n = params.numel()
     stream = torch.cuda.Stream(dev)
+    side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    # The iter_size = 2 accumulation iterations between optimizer steps are independent (same parameters, gradients
+    # summed), so they run CONCURRENTLY: two side streams, two workspaces, two gradient buffers that meet in the
+    # Adam kernel (g + g2 is bitwise what in-place accumulation gives).  One graph replay = 2 iterations + Adam.
+    ws = [plan.ws, plan.new_ws()]
+    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
+                    used=clip['used_instruments'], bpm_target=float(clip['bpm_int']), ws=ws[1])
+    grads = [gparams, torch.zeros_like(gparams)]
+    loss_out = [losses, torch.zeros_like(losses)]
+    P = nat.ptr
 
-    def iteration():
-        plan.train_iteration(params, gparams, xp, xu, losses)
+    def iteration(j=0):
+        plan.train_iteration(params, grads[j], xp, xu, loss_out[j], ws=ws[j])
+
+    def pair():
+        for j in (0, 1):
+            side[j].wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side[j]):
+                iteration(j)
+        for j in (0, 1):
+            torch.cuda.current_stream(dev).wait_stream(side[j])
 
     def optimizer_step():
+        st = nat.current_stream(dev)
         if dist is not None:
-            dist.all_reduce(gparams, op=dist.ReduceOp.SUM)          # sum, not mean: train-model.py:126,151-153
-        nat.check(native.lib.mst_adam_step(nat.ptr(params), nat.ptr(gparams), nat.ptr(m), nat.ptr(v), n, nat.ptr(state),
-                                           .01, .9, .999, 1e-8, 200, .9, 1, nat.current_stream(dev)), 'mst_adam_step')
+            grads[0].add_(grads[1])
+            grads[1].zero_()
+            dist.all_reduce(grads[0], op=dist.ReduceOp.SUM)          # sum, not mean: train-model.py:126,151-153
+            nat.check(native.lib.mst_adam_step(P(params), P(grads[0]), P(m), P(v), n, P(state), .01, .9, .999, 1e-8, 200, .9,
+                                               1, st), 'mst_adam_step')
+        else:
+            nat.check(native.lib.mst_adam_step2(P(params), P(grads[0]), P(grads[1]), P(m), P(v), n, P(state), .01, .9, .999,
+                                                1e-8, 200, .9, 1, st), 'mst_adam_step2')
 
-    graph_it = None
+    graph_pair = None
     with torch.cuda.stream(stream):
-        iteration(); iteration(); optimizer_step()                    # load code objects, size RCCL buffers
+        pair(); optimizer_step()                                      # load code objects, size RCCL buffers
         stream.synchronize()
         if not args.no_graph:
-            graph_it = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_it, stream=stream):
-                iteration()
-        run_it = graph_it.replay if graph_it is not None else iteration
+            graph_pair = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_pair, stream=stream):
+                pair()
+                if dist is None:
+                    optimizer_step()
 
-        def step(i):
-            run_it()
-            if (i + 1) % ITER_SIZE == 0:
+        def two_steps():
+            if graph_pair is not None:
+                graph_pair.replay()
+                if dist is not None:
+                    optimizer_step()
+            else:
+                pair()
                 optimizer_step()
 
-        for i in range(args.warmup):
-            step(i)
+        def run(nsteps):
+            for _ in range(nsteps // ITER_SIZE):
+                two_steps()
+            for _ in range(nsteps % ITER_SIZE):
+                iteration(0)                                          # odd tail: an accumulation iteration without a step
+
+        run(args.warmup)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        for i in range(args.steps):
-            step(i)
+        run(args.steps)
         ev1.record(stream)
         torch.cuda.synchronize()
         if dist is not None:
@@ -217,7 +250,8 @@ def main():
                config=dict(workload='one 30 s clip per GPU as piano-roll C=4,R=16,T=4 (+percussion), full widths '
                                     '(980325 params), fwd+loss+bwd every step, Adam+StepLR every 2nd step '
                                     '(BASELINE.json configs[1])',
-                           clips_per_gpu=1, iter_size=ITER_SIZE, hip_graph=graph_it is not None,
+                           clips_per_gpu=1, iter_size=ITER_SIZE, hip_graph=graph_pair is not None,
+                           concurrent_accumulation_iterations=2,
                            launches_per_iteration=plan.launch_count(7, False) + plan.launch_count(7, True) + 5,
                            parallelism=f'dp{world} (RCCL all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
                            device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))

@@ -123,6 +123,13 @@ int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_av
                       float* state, double lr0, double beta1, double beta2, double eps,
                       int32_t step_size, double gamma, int32_t zero_grad, mst_stream stream);
 
+/* Same step over the SUM of two gradient buffers: the iter_size = 2 accumulation iterations of
+ * train-model.py:126,151-153 are independent, so they may run concurrently (two streams, two workspaces,
+ * two gradient buffers) and meet here; grads + grads2 equals accumulating in place, bit for bit. */
+int32_t mst_adam_step2(float* params, float* grads, float* grads2, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float* state, double lr0, double beta1, double beta2, double eps,
+                       int32_t step_size, double gamma, int32_t zero_grad, mst_stream stream);
+
 /* ---- hard_output (style/model.py:818-832): n_pos positions x nfeat (5 or 2) features.
  * Like the reference it also zeroes sub-threshold velocities of `x` in place. */
 int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_stream stream);

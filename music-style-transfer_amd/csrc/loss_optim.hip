@@ -324,32 +324,46 @@ __global__ void adam_prepare_kernel(float* state, double lr0, double b1, double 
     state[2] = (float)sqrt(bc2);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, const float* __restrict__ state,
-                                                   float b1, float b2, float eps, int zero_grad) {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ g2,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const float* __restrict__ state, float b1, float b2, float eps, int zero_grad) {
     const float step = state[1], bc2s = state[2];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
+        // g2: gradients of a second, concurrently run accumulation iteration (same sum as accumulating in place)
+        const float gi = g2 ? g[i] + g2[i] : g[i];
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= step * (mi / (sqrtf(vi) / bc2s + eps));
-        if (zero_grad) g[i] = 0.f;
+        if (zero_grad) { g[i] = 0.f; if (g2) g2[i] = 0.f; }
     }
 }
 
-extern "C" int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                                 double lr0, double beta1, double beta2, double eps, int32_t step_size, double gamma,
-                                 int32_t zero_grad, mst_stream stream) {
+static int32_t adam_launch(float* params, float* grads, float* grads2, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                           double lr0, double beta1, double beta2, double eps, int32_t step_size, double gamma,
+                           int32_t zero_grad, mst_stream stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n <= 0 || step_size <= 0) return MST_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, s, state, lr0, beta1, beta2, (int)step_size, gamma);
     int64_t nb = (n + 1023) / 1024;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, grads2, exp_avg, exp_avg_sq, n,
                        (const float*)state, (float)beta1, (float)beta2, (float)eps, (int)zero_grad);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+extern "C" int32_t mst_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                 double lr0, double beta1, double beta2, double eps, int32_t step_size, double gamma,
+                                 int32_t zero_grad, mst_stream stream) {
+    return adam_launch(params, grads, nullptr, exp_avg, exp_avg_sq, n, state, lr0, beta1, beta2, eps, step_size, gamma, zero_grad, stream);
+}
+
+extern "C" int32_t mst_adam_step2(float* params, float* grads, float* grads2, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float* state, double lr0, double beta1, double beta2, double eps, int32_t step_size,
+                                  double gamma, int32_t zero_grad, mst_stream stream) {
+    if (!grads2) return MST_ERR_ARG;
+    return adam_launch(params, grads, grads2, exp_avg, exp_avg_sq, n, state, lr0, beta1, beta2, eps, step_size, gamma, zero_grad, stream);
 }
 
 // ------------------------------------------------------------------ hard_output

@@ -59,6 +59,8 @@ _SIGS = {
     'mst_train_iteration': (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'mst_adam_step': (C.c_int32, [_P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_int32, C.c_double, C.c_int32, _P]),
+    'mst_adam_step2': (C.c_int32, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_int32, C.c_double, C.c_int32, _P]),
     'mst_hard_output': (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P]),
     'mst_plan_step_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
     'mst_plan_step_info': (C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
