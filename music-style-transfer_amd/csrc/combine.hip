@@ -33,7 +33,7 @@ __device__ __forceinline__ int64_t elem_off(const CombineDesc& d, int64_t e) {
 
 // part[blk*(MAXC+1) + c] = partial sum of squares of slice c over this workgroup's elements
 __global__ __launch_bounds__(256) void combine_sumsq_kernel(const CombineDesc* __restrict__ descs, Bases b) {
-    const CombineDesc& d = descs[blockIdx.y];
+    const CombineDesc d = descs[blockIdx.y];     // by value: fields stay in registers across barriers
     if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float part[4][COMBINE_MAXC + 1];
     __shared__ float red[COMBINE_MAXC + 1];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void combine_sumsq_kernel(const CombineDesc* _
 
 // norms from the partials, then out = sum_c x_c n_c / S
 __global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* __restrict__ descs, Bases b) {
-    const CombineDesc& d = descs[blockIdx.y];
+    const CombineDesc d = descs[blockIdx.y];     // by value: fields stay in registers across barriers
     if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float nrm[COMBINE_MAXC + 1];
     __shared__ float part[4][COMBINE_MAXC + 1];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* _
 
 // part[blk*(MAXC+1) + c] = partial a_c, part[blk*(MAXC+1) + Cn] = partial b
 __global__ __launch_bounds__(256) void combine_bwd_reduce_kernel(const CombineDesc* __restrict__ descs, Bases b) {
-    const CombineDesc& d = descs[blockIdx.y];
+    const CombineDesc d = descs[blockIdx.y];     // by value: fields stay in registers across barriers
     if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float part[4][COMBINE_MAXC + 1];
     __shared__ float red[COMBINE_MAXC + 1];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void combine_bwd_reduce_kernel(const CombineDe
 }
 
 __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDesc* __restrict__ descs, Bases b) {
-    const CombineDesc& d = descs[blockIdx.y];
+    const CombineDesc d = descs[blockIdx.y];     // by value: fields stay in registers across barriers
     if ((int)blockIdx.x >= d.nblk) return;
     __shared__ float coef[COMBINE_MAXC + 1];
     __shared__ float nc_s[COMBINE_MAXC + 1];

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict
     // flat 1-D grid: member y owns workgroups [blk_begin, blk_begin + tiles * ksplit)
     int y = 0;
     while (y + 1 < count && (int)blockIdx.x >= descs[y + 1].blk_begin) ++y;
-    const GemmDesc& d = descs[y];                    // uniform: read through the scalar cache
+    const GemmDesc d = descs[y];                     // by value (scalar loads once): a reference would be re-read after every barrier
     const int local = blockIdx.x - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
     const int tile = local % ntile, split = local / ntile;
@@ -264,7 +264,7 @@ int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b,
 // concatenated feature axis (coalesced stores, broadcast/coalesced loads).  Its backward is the
 // segment reduce below applied to the gradient of the materialised tensor.
 __global__ __launch_bounds__(256) void gather_kernel(const GatherDesc* __restrict__ descs, Bases b) {
-    const GatherDesc& d = descs[blockIdx.y];
+    const GatherDesc& d = descs[blockIdx.y];       // no barriers here; dynamic seg[] indexing wants it in memory
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int row = blockIdx.x * 4 + wv; row < d.rows; row += gridDim.x * 4) {
         unsigned t = (unsigned)row;
@@ -299,7 +299,7 @@ int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipSt
 // stage 2 sums in chunk order (deterministic; no float atomics).
 #define SEGRED_CHUNK 64
 __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
-    const SegRedDesc& d = descs[blockIdx.y];
+    const SegRedDesc d = descs[blockIdx.y];
     if ((int)blockIdx.x >= d.nidx * d.nchunk) return;
     const int idx = blockIdx.x / d.nchunk, chunk = blockIdx.x - idx * d.nchunk;
     __shared__ float part[4][64];
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
 }
 
 __global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
-    const SegRedDesc& d = descs[blockIdx.y];
+    const SegRedDesc d = descs[blockIdx.y];
     if (d.nchunk == 1) return;
     const int total = d.nidx * d.width;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -362,7 +362,7 @@ int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int st
 // exactly like loss.backward() does in train-model.py:126.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __restrict__ ents, const SlabBlock* __restrict__ blocks, Bases b) {
     const SlabBlock blk = blocks[blockIdx.x];       // 1024 consecutive elements of one entry
-    const SlabEntry& e = ents[blk.entry];
+    const SlabEntry e = ents[blk.entry];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = blk.start + q * 256 + threadIdx.x;

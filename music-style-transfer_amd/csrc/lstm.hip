@@ -19,9 +19,10 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// REG (H <= 64) launches at most 256 lanes, so it may use the whole register file of one wave per SIMD
 template <bool REG>
-__global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
-    const LstmDesc& d = descs[blockIdx.y];
+__global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];        // by value: no descriptor re-reads after the per-step barriers
     const int bi = blockIdx.x;
     if (bi >= d.B) return;
     const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(1024) void lstm_fwd_kernel(const LstmDesc* __restri
 }
 
 template <bool REG>
-__global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
-    const LstmDesc& d = descs[blockIdx.y];
+__global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];        // by value: no descriptor re-reads after the per-step barriers
     const int bi = blockIdx.x;
     if (bi >= d.B) return;
     const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(1024) void lstm_bwd_kernel(const LstmDesc* __restri
 
 // W_hh (4H x H) -> W_hh^T (H x 4H) so that the H > 64 forward reads it lane-contiguously
 __global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __restrict__ descs, Bases b) {
-    const LstmDesc& d = descs[blockIdx.y];
+    const LstmDesc d = descs[blockIdx.y];        // by value: no descriptor re-reads after the per-step barriers
     if (d.H <= 64) return;
     const int G = 4 * d.H, n = G * d.H;
     const float* w = b.p[SP_PAR] + d.whh_off;
