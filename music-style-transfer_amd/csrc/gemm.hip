@@ -9,7 +9,7 @@
 // side) are fused into the tile load / epilogue.
 //
 // Tiling: 32x32 outputs x KD-deep k-tile (KD = 32 / 64 / 128 by the descriptor's k range) per
-// 256-thread workgroup; the four waves split the k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
+// 512-thread workgroup; the eight waves split the k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
 // float4 fragment reads).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
 // tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
 // Independent GEMMs share one launch: the 1-D grid is the concatenation of every member's
@@ -127,16 +127,17 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-    constexpr int NL = GEMM_BM * KD / 256;           // tile elements per lane and operand (4 / 8 / 16)
-    constexpr int KW = KD / 4;                       // k rows of the tile each wave reduces
+    constexpr int NT = GEMM_THREADS, NW = NT / 64;
+    constexpr int NL = GEMM_BM * KD / NT;            // tile elements per lane and operand (2 / 4 / 8)
+    constexpr int KW = KD / NW;                      // k rows of the tile each wave reduces
     float va[NL], ya[NL], vb[NL];
 
-    // element e = tid + 256*i of the 32 x KD tile: (row, k) = (e / KD, e % KD) when lanes walk k,
+    // element e = tid + NT*i of the 32 x KD tile: (row, k) = (e / KD, e % KD) when lanes walk k,
     // (e % 32, e / 32) when lanes walk the row index
-#define A_ROW(i) (AKF ? (tid / KD) + (256 / KD) * (i) : (tid & 31))
-#define A_KL(i) (AKF ? (tid % KD) : (tid >> 5) + 8 * (i))
-#define B_ROW(i) (BKF ? (tid / KD) + (256 / KD) * (i) : (tid & 31))
-#define B_KL(i) (BKF ? (tid % KD) : (tid >> 5) + 8 * (i))
+#define A_ROW(i) (AKF ? (tid / KD) + (NT / KD) * (i) : (tid & 31))
+#define A_KL(i) (AKF ? (tid % KD) : (tid >> 5) + (NT / 32) * (i))
+#define B_ROW(i) (BKF ? (tid / KD) + (NT / KD) * (i) : (tid & 31))
+#define B_KL(i) (BKF ? (tid % KD) : (tid >> 5) + (NT / 32) * (i))
 #define GEMM_ISSUE(KT)                                                                                     \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
@@ -188,8 +189,8 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 #undef A_KL
 #undef B_ROW
 #undef B_KL
-    // sum the four waves' partial tiles (fixed order) and run the epilogue, 4 outputs per lane
-    float* red = &As[0][0];                          // 4 x 32 x 32 floats fit in the A tile
+    // sum the waves' partial tiles (fixed order) and run the epilogue
+    float* red = &As[0][0];                          // NW x 32 x 32 floats fit in the A+B tile storage (contiguous)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -198,10 +199,12 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     float* cbase = b.p[d.out.space] + d.out.off;
     const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int o = tid + q * 256;
+    for (int q = 0; q < GEMM_BM * GEMM_BN / NT; ++q) {
+        const int o = tid + q * NT;
         const int m = tm * GEMM_BM + o / GEMM_BN, n = tn * GEMM_BN + o % GEMM_BN;
-        const float v = (red[o] + red[GEMM_BM * GEMM_BN + o]) + (red[2 * GEMM_BM * GEMM_BN + o] + red[3 * GEMM_BM * GEMM_BN + o]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w * (GEMM_BM * GEMM_BN) + o];
         if (m < M && n < N) store_out<OK>(d, cbase, bias, m, n, split, v);
     }
 }
@@ -210,9 +213,12 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
 // all small Linears of one dependency level — into a single launch.
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, Bases b) {
-    __shared__ float As[GEMM_BK][GEMM_BM + 4];
-    __shared__ float Bs[GEMM_BK][GEMM_BN + 4];
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, Bases b) {
+    // A tile | B tile; the final reduce overlays the whole block with one 32x32 partial tile per wave
+    constexpr int TILE_F = GEMM_BK * (GEMM_BM + 4), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
+    __shared__ float smem[(2 * TILE_F > RED_F) ? 2 * TILE_F : RED_F];
+    float (*As)[GEMM_BM + 4] = reinterpret_cast<float (*)[GEMM_BM + 4]>(smem);
+    float (*Bs)[GEMM_BN + 4] = reinterpret_cast<float (*)[GEMM_BN + 4]>(smem + TILE_F);
     // flat 1-D grid: member y owns workgroups [blk_begin, blk_begin + tiles * ksplit)
     int y = 0;
     while (y + 1 < count && (int)blockIdx.x >= descs[y + 1].blk_begin) ++y;
@@ -253,7 +259,7 @@ int gemm_variant(const GemmDesc& g) {
 
 int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b, hipStream_t s) {
     if (count <= 0 || total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(gemm_kernel, dim3(total_blocks), dim3(256), 0, s, dev_descs, count, b);
+    hipLaunchKernelGGL(gemm_kernel, dim3(total_blocks), dim3(GEMM_THREADS), 0, s, dev_descs, count, b);
     return (int)hipGetLastError();
 }
 

@@ -187,4 +187,4 @@ bool notes_widths_supported(int W, int CW, int ML);
 #define GEMM_BM 32
 #define GEMM_BN 32
 #define GEMM_BK 128     // k-tile staged in LDS per step
-#define GEMM_KW 32      // k rows of the tile each of the 4 waves reduces
+#define GEMM_THREADS 1024 // lanes per workgroup: 16 waves split every k-tile
