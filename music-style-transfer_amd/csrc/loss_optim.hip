@@ -145,18 +145,23 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
                                                        float* losses, float* saved) {
     __shared__ float sums[N_TAPE_IN];
     const int tid = threadIdx.x;
-    if (tid < 14) {
-        // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; inputs 0..6 are the pitched tensor's,
-        // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}
-        const bool pitched = tid < 7;
-        const int k = pitched ? tid : tid - 7;
+    // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; tape inputs 0..6 are the pitched tensor's,
+    // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}.  Lanes stride over the per-workgroup partials,
+    // then a fixed-order wave reduction (the tail is one 64-lane wave).
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+        const bool pitched = k < 7;
+        const int kk = pitched ? k : k - 7;
         const float* src = scratch + (pitched ? 0 : LOSS_MAXBLK * 8);
         const int nb = pitched ? nblk_p : (has_u ? nblk_u : 0);
         float s = 0.f;
-        for (int q = 0; q < nb; ++q) s += src[q * 8 + k];
-        if (pitched) sums[k] = s;
-        else if (k < 5) sums[7 + k] = s;
-        else if (k == 6) sums[12] = s;
+        for (int q = tid; q < nb; q += 64) s += src[q * 8 + kk];
+        s = wave_sum(s);
+        if (tid == 0) {
+            if (pitched) sums[kk] = s;
+            else if (kk < 5) sums[7 + kk] = s;
+            else if (kk == 6) sums[12] = s;
+        }
     }
     // instruments: BCE-with-logits, mean over ni (style/model.py:903)
     float v = 0.f;
