@@ -199,7 +199,9 @@ struct mst_plan {
     std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<SlabEntry> slabs[3];
     std::vector<Op> ops;
     // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
-    std::vector<Step> sched[2];
+    std::vector<Step> sched[2];        // per-stage merging (stages may run separately)
+    std::vector<Step> sched_all[2];    // stage-agnostic merging, used when all stages run together
+    const std::vector<Step>& list(int mask, int backward) const { return mask == MST_STAGE_ALL ? sched_all[backward ? 1 : 0] : sched[backward ? 1 : 0]; }
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
     std::vector<CombineDesc> s_combines;
     std::map<std::string, T> named;
@@ -439,7 +441,7 @@ struct mst_plan {
 
     void build();
     void accesses(const Step& s, std::vector<Acc>& out) const;
-    void schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out);
+    void schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out, bool across_stages);
     void schedule();
     int upload();
 };
@@ -778,7 +780,7 @@ static bool conflicts(const std::vector<Acc>& a, const std::vector<Acc>& b) {
     return false;
 }
 
-void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out) {
+void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out, bool across_stages) {
     const int n = (int)seq.size();
     std::vector<std::vector<Acc>> acc(n);
     std::vector<int> level(n, 0);
@@ -806,7 +808,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             for (int j = i; j < n; ++j) {
                 if (done[j] || level[j] != lv) continue;
                 const Step& s = seq[j];
-                if (s.kind != s0.kind || s.stage != s0.stage) continue;
+                if (s.kind != s0.kind || (!across_stages && s.stage != s0.stage)) continue;
                 // LSTM launches come in a register-resident (H <= 64) and an L2 flavour
                 if ((s.kind == K_LSTM_F || s.kind == K_LSTM_B || s.kind == K_LSTM_T) && ((s.b > 64) != (s0.b > 64))) continue;
                 if (j != i && !mergeable) continue;
@@ -820,6 +822,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                     else if (s.kind == K_COMB_F || s.kind == K_COMB_B) s_combines.push_back(combines[s.first + q]);
                 }
                 m.count += s.count;
+                m.stage |= s.stage;
                 if (s.a > m.a) m.a = s.a;
                 if (s.b > m.b) m.b = s.b;
             }
@@ -841,8 +844,10 @@ void mst_plan::schedule() {
     std::vector<Step> fwd, bwd;
     for (auto& op : ops) for (auto s : op.fwd) { s.stage = op.stage; fwd.push_back(s); }
     for (size_t i = ops.size(); i-- > 0;) for (auto s : ops[i].bwd) { s.stage = ops[i].stage; bwd.push_back(s); }
-    schedule_pass(fwd, sched[0]);
-    schedule_pass(bwd, sched[1]);
+    schedule_pass(fwd, sched[0], false);
+    schedule_pass(bwd, sched[1], false);
+    schedule_pass(fwd, sched_all[0], true);
+    schedule_pass(bwd, sched_all[1], true);
 }
 
 template <class D>
@@ -904,7 +909,7 @@ extern "C" int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t*
 extern "C" int32_t mst_plan_launch_count(const mst_plan* p, int32_t mask, int32_t backward) {
     if (!p) return MST_ERR_ARG;
     int n = 0;
-    for (auto& s : p->sched[backward ? 1 : 0]) {
+    for (auto& s : p->list(mask, backward)) {
         if (!(s.stage & mask)) continue;
         n += (s.kind == K_COMB_F || s.kind == K_COMB_B || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
     }
@@ -944,7 +949,7 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
     if (!p || !params || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, nullptr, ws, pitched, unpitched);
-    for (auto& s : p->sched[0]) {
+    for (auto& s : p->list(mask, 0)) {
         if (!(s.stage & mask)) continue;
         int e = run_step(p, s, b, (hipStream_t)stream);
         if (e) return e < 0 ? e : MST_ERR_LAUNCH;
@@ -972,7 +977,7 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     if (!p || !params || !gparams || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
-    for (auto& s : p->sched[1]) {
+    for (auto& s : p->list(mask, 1)) {
         if (!(s.stage & mask)) continue;
         int e = run_step(p, s, b, (hipStream_t)stream);
         if (e) return e < 0 ? e : MST_ERR_LAUNCH;
@@ -1084,7 +1089,7 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
 extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t backward) {
     if (!p) return MST_ERR_ARG;
     int n = 0;
-    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) ++n;
+    for (auto& s : p->list(mask, backward)) if (s.stage & mask) ++n;
     return n;
 }
 
@@ -1093,7 +1098,7 @@ extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t 
 extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 5 per step */) {
     if (!p || !info) return MST_ERR_ARG;
     std::vector<const Step*> steps;
-    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) steps.push_back(&s);
+    for (auto& s : p->list(mask, backward)) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
         int32_t* o = info + 5 * idx++;
@@ -1116,7 +1121,7 @@ extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t 
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MST_ERR_ALLOC;
     std::vector<const Step*> steps;
-    for (auto& s : p->sched[backward ? 1 : 0]) if (s.stage & mask) steps.push_back(&s);
+    for (auto& s : p->list(mask, backward)) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
         run_step(p, *s, b, st);                       // warm
