@@ -153,6 +153,9 @@ def main():
         plan.train_iteration(params, grads[j], xp, xu, loss_out[j], ws=ws[j])
 
     def pair():
+        if os.environ.get('MST_BENCH_SEQ'):      # experiment: accumulation iterations back to back on one stream
+            iteration(0); iteration(1)
+            return
         for j in (0, 1):
             side[j].wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side[j]):

@@ -44,3 +44,9 @@ def test_oracle_long_clip_config5_shape(native):
     # 32-bit index math, the 256-slab weight-gradient splits and long (151-step) LSTM chains at 9.4x the bench clip
     e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 8, 151, 4, True, clip_id=9)
     print('long clip: all-gradient rel-L2', e, 'worst tensor', worst)
+
+
+def test_dataflow_lanes_opt_in_parity(native, monkeypatch):
+    # MST_LANES > 1 spreads independent launches over internal side streams with event edges (experimental)
+    monkeypatch.setenv('MST_LANES', '4')
+    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 3, True, check_bitwise=True)

@@ -1,0 +1,29 @@
+import sys, os, faulthandler
+faulthandler.enable()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'music-style-transfer_amd')]
+import torch
+from bench import CLIP, WIDTHS, init_params
+from oracle.synth import synth_clip
+from style import _native as nat
+dev = torch.device('cuda:0'); native = nat.get()
+dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+flat, table = init_params(native, dims); clip = synth_clip(0, 4, 16, 4, True)
+plan = native.plan(dims, dev)
+plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'], used=clip['used_instruments'], bpm_target=120.)
+params = flat.to(dev); g = torch.zeros_like(params); xp, xu = clip['pitched'].to(dev), clip['unpitched'].to(dev)
+s = torch.cuda.Stream(dev)
+with torch.cuda.stream(s):
+    plan.forward(7, params, xp, xu); s.synchronize(); print('eager fwd ok', flush=True)
+    gr = torch.cuda.CUDAGraph()
+    print('begin capture', flush=True)
+    with torch.cuda.graph(gr, stream=s):
+        plan.forward(7, params, xp, xu)
+    print('captured fwd', flush=True)
+    gr.replay(); s.synchronize(); print('replayed fwd', flush=True)
+    plan.train_iteration(params, g, xp, xu); s.synchronize()
+    gr2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr2, stream=s):
+        plan.train_iteration(params, g, xp, xu)
+    print('captured iteration', flush=True)
+    gr2.replay(); s.synchronize(); print('replayed iteration', flush=True)
