@@ -1,30 +1,97 @@
-"""Host-side tensor preparation with the reference's names (style/data.py:19-31,122-169).
-
-Only the parts the model path needs are here: the instrument vocabulary / one-hot encoding,
-`prepare_input` and `get_used_instruments`.  MIDI parsing and piano-roll conversion
-(style/midi*.py, iter_inputs / get_input) stay on the host and are the next scope row;
-they depend on `mido`, which this build does not use.
+"""Host-side data pipeline with the reference's names (style/data.py:19-169): instrument vocabulary and
+one-hot encoding, MIDI file -> model input (`iter_inputs`, `get_input`), `prepare_input`,
+`get_used_instruments`.  Everything here runs on the host, per song; only `prepare_input` touches the
+device (one H2D copy per tensor).  sklearn's OneHotEncoder and pandas are not used: categories are the
+sorted distinct values, which is what `categories='auto'` produces (style/data.py:23-27).
 """
 import numpy as np
 import torch
 
+from style.exceptions import MidiFormatError
+from style.midi import load_midi_from_file, is_pitched, program2instrument, program2group, popular_instruments
+from style.midi_conversion import read_midi, ChannelConverter, NoteTable, _key_weights
 from style.model import device
+from style.scales import key_names, get_scale, major_mode
 
-# the 40 most popular General-MIDI programs, in the reference's order (style/midi.py:23-64)
-included_instruments = [0, 25, 48, 33, 1, 27, 49, 29, 35, 30, 50, 24, 5, 4, 32, 52, 26, 18, 28, 89, 65, 53, 61, 2, 17, 73,
-                        54, 62, 16, 39, 34, 51, 90, 56, 66, 38, 11, 81, 3, 57]
-# General-MIDI family of a program = program // 8 (style/midi_programs.txt)
-_GM_FAMILIES = ['Piano', 'Chromatic Percussion', 'Organ', 'Guitar', 'Bass', 'Strings', 'Ensemble', 'Brass', 'Reed', 'Pipe',
-                'Synth Lead', 'Synth Pad', 'Synth Effects', 'Ethnic', 'Percussive', 'Sound effects']
-program2group = {p: _GM_FAMILIES[p // 8] for p in range(128)}
+included_instruments = popular_instruments
 instrument_groups = [program2group[p] for p in included_instruments]
-# OneHotEncoder(categories='auto') orders categories by sorted value (style/data.py:23-27)
 _instrument_categories = sorted(set(included_instruments))
 _group_categories = sorted(set(instrument_groups))
 n_instruments = len(included_instruments) + 1            # also percussion
 instrument_size = len(_group_categories) + len(_instrument_categories)   # 51
 percussion_id = len(included_instruments)
-major_mode = 'major'
+
+
+def iter_all_midis(files, shuffle=False, looped=False):
+    """(file, channels, info) of every readable file; unreadable files and MidiFormatErrors are skipped."""
+    if shuffle:
+        files = files[:]
+        np.random.shuffle(files)
+    while True:
+        for file in files:
+            mid = load_midi_from_file(file)
+            if mid is None:
+                continue
+            try:
+                channels, info = read_midi(mid)
+            except MidiFormatError:
+                continue
+            yield file, channels, info
+        if not looped:
+            return
+
+
+def iter_inputs(files, instruments, min_n_messages=100, *args, **kwargs):
+    for filename, channels, info in iter_all_midis(files, *args, **kwargs):
+        channels = [c for c in channels
+                    if c['instrument_id'] in [-1, *instruments] and len(c['messages']) >= min_n_messages]
+        if not any(is_pitched(c['instrument_id']) for c in channels):
+            continue
+        try:
+            yield filename, get_input(channels, info)
+        except Exception:
+            print(filename)
+            raise
+
+
+def merge_nchannels(nchannels):
+    """Channels playing the same instrument become one, notes ordered by onset (stable) (:103-114)."""
+    instrument_ids = {n['instrument_id'] for n in nchannels}
+    assert len(instrument_ids) == 1
+    instrument_id = instrument_ids.pop()
+    notes = NoteTable.concat([n['notes'] for n in nchannels])
+    return {
+        'channel_id': min(n['channel_id'] for n in nchannels),
+        'instrument_id': instrument_id,
+        'instrument_name': program2instrument[instrument_id],
+        'notes': notes.take(np.argsort(notes.time, kind='stable')),
+    }
+
+
+def get_input(channels, info):
+    """channels, info -> (info + detected scale, pitched rolls (C,R,T,10,56,5), instrument features
+    (C,51), instrument ids, unpitched rolls (1,R,T,10,47,2) | None) (:66-100)."""
+    cc = ChannelConverter(info)
+    by_instrument = {}
+    for channel in channels:
+        by_instrument.setdefault(channel['instrument_id'], []).append(cc.channel2nchannel(channel))
+    nchannels = [merge_nchannels(group) for group in by_instrument.values()]
+    pitched = [n for n in nchannels if is_pitched(n['instrument_id'])]
+    unpitched = [n for n in nchannels if not is_pitched(n['instrument_id'])]
+
+    # seconds per pitch class: rows = keys, columns = channels; absent keys count 0 (DataFrame.sum skips NaN)
+    seconds = np.zeros((len(key_names), len(pitched)))
+    for j, nchannel in enumerate(pitched):
+        weights, present = _key_weights(info, nchannel)
+        seconds[present, j] = weights[present]
+    keys_dist = seconds.sum(axis=1)
+    keys_dist /= keys_dist.sum()
+    info['scale'] = get_scale(keys_dist=keys_dist)
+
+    pitched_vchannels = np.stack([cc.nchannel2vchannel(n) for n in pitched])
+    unpitched_vchannels = np.stack([cc.nchannel2vchannel(n) for n in unpitched]) if unpitched else None
+    instruments = [n['instrument_id'] for n in pitched]
+    return info, pitched_vchannels, encode_instruments(instruments), instruments, unpitched_vchannels
 
 
 def encode_instruments(instruments):
@@ -46,8 +113,7 @@ def prepare_input(input, max_n_bars=None):
     instruments_features = torch.tensor(instruments_features, dtype=torch.float).to(device).unsqueeze(0)
     if unpitched_channels is not None:
         unpitched_channels = torch.tensor(unpitched_channels[:, :max_n_bars], dtype=torch.float).to(device).unsqueeze(0)
-    mode_name = info['scale']['mode']
-    is_major = mode_name == major_mode or getattr(mode_name, 'name', None) == major_mode
+    is_major = info['scale']['mode'] in (major_mode, 'major')
     mode = torch.tensor([[1., 0.]] if is_major else [[0., 1.]]).to(device)
     bpm = torch.tensor(info['bpm'], dtype=torch.float).unsqueeze(0).to(device)
     return mode, bpm, pitched_channels, instruments_features, unpitched_channels
