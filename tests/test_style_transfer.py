@@ -1,0 +1,123 @@
+"""Inference driver (style/style_transfer.py:22-158).
+
+CPU part: the per-song host decisions (instrument pick, info merge, channel slots).
+GPU part (-m gpu): `transfer_style` end to end on two of the reference's own example files with the
+seed-108 full-width model — directory layout, `original/*.mid` is the fixed point the reference wrote,
+the reconstructed / styled songs against the torch-CPU oracle driven through the same host code.
+"""
+import collections
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MIDI = os.path.join(HERE, 'golden', 'midi')
+COMPOSITION = os.path.join(MIDI, 'Minuetto in sol magg. BWV App. 114.mid')
+STYLE = os.path.join(MIDI, 'Nocturne No. 1 in E minor, Op. 72_ Andante.mid')
+
+
+def test_select_instruments():
+    from style.style_transfer import select_instruments
+    from style.data import included_instruments, percussion_id
+    cats = sorted(included_instruments)
+    logits = np.full(41, -5.)
+    logits[[3, 7, percussion_id]] = [2., 1., 3.]
+    programs, unpitched = select_instruments(logits, 2)
+    assert programs == [cats[3]] and unpitched                   # percussion takes one of the two picks
+    programs, unpitched = select_instruments(logits, 1)
+    assert programs == [cats[3]] and unpitched                   # lone percussion pick is widened by one
+    logits[percussion_id] = -9.
+    programs, unpitched = select_instruments(logits, 2)
+    assert programs == [cats[3], cats[7]] and not unpitched
+    programs, unpitched = select_instruments(logits, 41)
+    assert len(programs) == 40 and unpitched and set(programs) == set(included_instruments)
+
+
+def test_combine_info_and_channel_slots():
+    from style.style_transfer import combine_info, channel_slots
+    style_info = dict(time_signature=dict(numerator=3), scale=dict(key='D', mode='m'), ticks_per_beat=96, ticks_per_bar=288,
+                      tempo=400000, duration=5)
+    melody_info = dict(time_signature=dict(numerator=4), scale=dict(key='C', mode='M'), ticks_per_beat=480, ticks_per_bar=1920,
+                       tempo=500000, duration=9)
+    info = combine_info(style_info=style_info, melody_info=melody_info)
+    assert info == dict(time_signature=dict(numerator=4), scale=dict(key='D', mode='m'), ticks_per_beat=480,
+                        ticks_per_bar=1920, tempo=400000)
+    assert info['scale'] is style_info['scale']                  # shared, apply_style writes the mode through it
+    pitched, unpitched = channel_slots(list(range(20)))
+    assert [c['channel_id'] for c in pitched] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15]
+    assert unpitched == {'channel_id': 9, 'instrument_id': -1}
+
+
+def _events(track):
+    program, now, events = {}, 0, collections.Counter()
+    for m in track:
+        now += m.time
+        if m.type == 'program_change':
+            program[m.channel] = m.program
+        elif m.type in ('note_on', 'note_off'):
+            events[(now, m.type, m.note, -1 if m.channel == 9 else program.get(m.channel, 0))] += 1
+    return events
+
+
+@pytest.mark.gpu
+def test_transfer_style_end_to_end(tmp_path):
+    from oracle import style_oracle as so
+    from style import smf, style_transfer as st
+    from style.data import prepare_input, encode_instruments
+    from style.midi_conversion import ChannelConverter
+    from style.scales import major_mode, minor_mode
+    from test_host_surface import FULL, build_model
+    model = build_model(FULL, seed=108).to('cuda:0')
+    out = str(tmp_path)
+    st.transfer_style(model, COMPOSITION, [STYLE], out)
+    name, sname = 'Minuetto in sol magg. BWV App. 114', 'Nocturne No. 1 in E minor, Op. 72_ Andante'
+    base = os.path.join(out, name)
+    files = {k: os.path.join(base, v) for k, v in dict(
+        original=f'original/{name}.mid', style_original=f'original/{sname}.mid', reconstructed=f'{name} (reconstructed).mid',
+        styled=f'{name} ({sname} style).mid').items()}
+    for p in files.values():
+        assert os.path.isfile(p), p
+    # the originals went file -> rolls -> GPU hard_output -> file; both inputs are fixed points of that
+    for k, src in (('original', COMPOSITION), ('style_original', STYLE)):
+        assert _events(smf.MidiFile(files[k]).tracks[0]) == _events(smf.MidiFile(src).tracks[0])
+
+    # oracle: same host code, torch-CPU model arithmetic
+    flat = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    P = so.Params(flat)
+
+    def oracle_extract(path):
+        inp = st.get_model_input(path)
+        mode, bpm, pitched, instr, unpitched = (None if t is None else t.cpu() for t in prepare_input(inp, 1000 // inp[1][1].shape[0]))
+        with torch.no_grad():
+            return inp, so.extract_style(flat, mode, bpm, pitched, instr, unpitched)
+
+    def oracle_apply(info, style, melody, rhythm, n_instruments):
+        with torch.no_grad():
+            ip, mp, bp = so.song_info(P.sub('song_info_model'), style, rhythm)
+            info['tempo'] = smf.bpm2tempo(round(float(bp)))
+            programs, unpitched = st.select_instruments(ip.numpy()[0], n_instruments)
+            info['scale']['mode'] = major_mode if int(mp[0].argmax()) == 0 else minor_mode
+            instr = torch.tensor(encode_instruments(programs), dtype=torch.float).unsqueeze(0)
+            xp = so.hard_output(so.pitched_style_applier(P.sub('pitched_style_applier'), style, melody, rhythm, instr))
+            xu = so.hard_output(so.unpitched_style_applier(P.sub('unpitched_style_applier'), style, rhythm)) if unpitched else None
+        infos, uinfo = st.channel_slots(programs)
+        mid = st.decode_rolls(ChannelConverter(info), infos, xp.numpy()[0], uinfo, None if xu is None else xu.numpy()[0, 0])
+        return mid, programs, unpitched
+
+    (_, (cinfo, _, _, cinstr, _)), (style_a, melody_a, rhythm_a) = oracle_extract(COMPOSITION)
+    (_, (sinfo, _, _, sinstr, _)), (style_b, _, _) = oracle_extract(STYLE)
+    want = {'reconstructed': oracle_apply(cinfo, style_a, melody_a, rhythm_a, len(cinstr))}
+    want['styled'] = oracle_apply(st.combine_info(style_info=sinfo, melody_info=cinfo), style_b, melody_a, rhythm_a, len(sinstr))
+    for k, (mid, programs, unpitched) in want.items():
+        got = smf.MidiFile(files[k])
+        head = lambda m: [(x.type, x.__dict__.get('tempo'), x.__dict__.get('program'), x.__dict__.get('numerator'))
+                          for x in m.tracks[0] if x.type in ('set_tempo', 'program_change', 'time_signature')]
+        assert head(got) == head(mid), k                          # same tempo, same instruments, same metre
+        assert got.ticks_per_beat == mid.ticks_per_beat
+        a, b = _events(got.tracks[0]), _events(mid.tracks[0])
+        n = sum(b.values())
+        differing = sum((a - b).values()) + sum((b - a).values())
+        # fp32 outputs within 1e-4 rel-L2 of the oracle; int(duration * ticks) may land one tick apart for a few notes
+        assert n > 1000 and differing <= 0.01 * n, (k, differing, n)
