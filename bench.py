@@ -102,6 +102,11 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel time table to stderr')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only to rehearse N>1 on one GPU')
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
+    ap.add_argument('--clips-per-gpu', type=int, default=1,
+                    help='B > 1: B different clips per GPU in one batched plan (BASELINE.json configs[2]/[3]); a step is then one '
+                         'clip-iteration, the optimizer steps once per pass over the B clips (iter_size = B per GPU)')
+    ap.add_argument('--accum', choices=['streams', 'batched'], default='streams',
+                    help='B = 1: run the iter_size = 2 accumulation iterations on two streams (default) or as one 2-clip batched pass')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -124,35 +129,53 @@ def main():
     from oracle.synth import synth_clip
     from style import _native as nat
     native = nat.get()                     # raises if libmst_amd.so is missing: no fallback
-    dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
-    flat, table = init_params(native, dims)
-    clip = synth_clip(rank, CLIP['C'], CLIP['R'], CLIP['T'], True)      # one clip per GPU
+    B = max(1, args.clips_per_gpu)
+    batched = B > 1 or args.accum == 'batched'
+    K = B if B > 1 else (ITER_SIZE if batched else 1)          # clips carried by every launch of the plan
+    iter_size = B if B > 1 else ITER_SIZE                        # clip-iterations between optimizer steps, per GPU
+    dims1 = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+    dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1, clips=K)
+    flat, table = init_params(native, dims1)
+    # B = 1: the one clip of this GPU (both accumulation iterations run on it, like the reference looping over a
+    # one-song dataset); B > 1: B different clips
+    clips = [synth_clip(rank * B + (k if B > 1 else 0), CLIP['C'], CLIP['R'], CLIP['T'], True) for k in range(K)]
+    clip = clips[0]
     plan = native.plan(dims, dev)
-    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
-                    used=clip['used_instruments'], bpm_target=float(clip['bpm_int']))
+
+    def set_all(ws=None):
+        for k, c in enumerate(clips):
+            plan.set_inputs(mode=c['mode'], bpm=c['bpm'], instr=c['instruments_features'], used=c['used_instruments'],
+                            bpm_target=float(c['bpm_int']), ws=ws, clip=k)
+
+    set_all()
     params = flat.to(dev)
     gparams = torch.zeros_like(params)
     m, v = torch.zeros_like(params), torch.zeros_like(params)
     state = torch.zeros(4, device=dev)
-    xp, xu = clip['pitched'].contiguous().to(dev), clip['unpitched'].contiguous().to(dev)
-    losses = torch.zeros(nat.N_LOSSES, device=dev)
+    xp = torch.cat([c['pitched'] for c in clips]).contiguous().to(dev)
+    xu = torch.cat([c['unpitched'] for c in clips]).contiguous().to(dev)
+    losses = torch.zeros(K, nat.N_LOSSES, device=dev)
     n = params.numel()
     stream = torch.cuda.Stream(dev)
     side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
     # The iter_size = 2 accumulation iterations between optimizer steps are independent (same parameters, gradients
-    # summed), so they run CONCURRENTLY: two side streams, two workspaces, two gradient buffers that meet in the
-    # Adam kernel (g + g2 is bitwise what in-place accumulation gives).  One graph replay = 2 iterations + Adam.
-    ws = [plan.ws, plan.new_ws()]
-    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
-                    used=clip['used_instruments'], bpm_target=float(clip['bpm_int']), ws=ws[1])
-    grads = [gparams, torch.zeros_like(gparams)]
-    loss_out = [losses, torch.zeros_like(losses)]
+    # summed).  'streams': they run CONCURRENTLY on two side streams with two workspaces and two gradient buffers that
+    # meet in the Adam kernel (g + g2 is bitwise what in-place accumulation gives).  'batched': they are the two clips of
+    # one 2-clip plan, every launch carrying both.  One graph replay = iter_size iterations + Adam either way.
+    ws = [plan.ws] if batched else [plan.ws, plan.new_ws()]
+    if not batched:
+        set_all(ws[1])
+    grads = [gparams] if batched else [gparams, torch.zeros_like(gparams)]
+    loss_out = [losses] if batched else [losses, torch.zeros_like(losses)]
     P = nat.ptr
 
     def iteration(j=0):
         plan.train_iteration(params, grads[j], xp, xu, loss_out[j], ws=ws[j])
 
     def pair():
+        if batched:
+            iteration(0)
+            return
         if os.environ.get('MST_BENCH_SEQ'):      # experiment: accumulation iterations back to back on one stream
             iteration(0); iteration(1)
             return
@@ -166,9 +189,11 @@ def main():
     def optimizer_step():
         st = nat.current_stream(dev)
         if dist is not None:
-            grads[0].add_(grads[1])
-            grads[1].zero_()
+            if not batched:
+                grads[0].add_(grads[1])
+                grads[1].zero_()
             dist.all_reduce(grads[0], op=dist.ReduceOp.SUM)          # sum, not mean: train-model.py:126,151-153
+        if dist is not None or batched:
             nat.check(native.lib.mst_adam_step(P(params), P(grads[0]), P(m), P(v), n, P(state), .01, .9, .999, 1e-8, 200, .9,
                                                1, st), 'mst_adam_step')
         else:
@@ -196,11 +221,14 @@ def main():
                 optimizer_step()
 
         def run(nsteps):
-            for _ in range(nsteps // ITER_SIZE):
+            for _ in range(nsteps // iter_size):
                 two_steps()
-            for _ in range(nsteps % ITER_SIZE):
-                iteration(0)                                          # odd tail: an accumulation iteration without a step
+            if not batched:
+                for _ in range(nsteps % iter_size):
+                    iteration(0)                                      # odd tail: an accumulation iteration without a step
 
+        if batched and args.steps % iter_size:
+            raise SystemExit(f'--steps must be a multiple of {iter_size} clip-iterations in batched mode')
         run(args.warmup)
         if dist is not None:
             dist.barrier()
@@ -215,7 +243,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
-        final_loss = float(losses.cpu()[0])
+        final_loss = float(losses.cpu()[0, 0])
         if dist is not None:
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -240,6 +268,7 @@ def main():
             roof = dict(bound='mfma', kernel=KIND_NAMES[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
                         flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
                         frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(KIND_NAMES[kind]),
+                        clips_per_launch=K,
                         whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
                                              achieved_tflops=algorithmic_flops_per_iter(**CLIP) / (dt / args.steps) / 1e12))
             if args.breakdown:
@@ -250,12 +279,15 @@ def main():
     out = dict(metric='style-transfer opt iters/sec', value=ips, unit='iters/s', n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload='one 30 s clip per GPU as piano-roll C=4,R=16,T=4 (+percussion), full widths '
-                                    '(980325 params), fwd+loss+bwd every step, Adam+StepLR every 2nd step '
-                                    '(BASELINE.json configs[1])',
-                           clips_per_gpu=1, iter_size=ITER_SIZE, hip_graph=graph_pair is not None,
-                           concurrent_accumulation_iterations=2,
-                           launches_per_iteration=plan.launch_count(7, False) + plan.launch_count(7, True) + 5,
+               config=dict(workload=(f'{B} different 30 s clips per GPU in one batched plan (BASELINE.json configs[2]/[3] shape), '
+                                     f'optimizer step after every pass over the {B} clips; a step = one clip-iteration'
+                                     if B > 1 else
+                                     'one 30 s clip per GPU (BASELINE.json configs[1])') +
+                                    ': piano-roll C=4,R=16,T=4 (+percussion), full widths (980325 params), fwd+loss+bwd every '
+                                    'step, Adam+StepLR every iter_size steps',
+                           clips_per_gpu=B, iter_size=iter_size, hip_graph=graph_pair is not None,
+                           accumulation=('batched plan, %d clips per launch' % K) if batched else '2 concurrent streams',
+                           launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 5,
                            parallelism=f'dp{world} (RCCL all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
                            device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))
     if rank == 0:

@@ -35,6 +35,10 @@ typedef struct {
     int32_t instr;              /* instrument_size (51) */
     int32_t n_instruments;      /* 41 */
     int32_t has_unpitched;      /* unpitched_channels is not None */
+    int32_t clips;              /* independent clips of this shape carried by every launch (0 or 1 = one clip).
+                                 * The reference is strictly batch 1 and sums gradients over iter_size songs
+                                 * (train-model.py:95,126,151-153); K clips here = K such iterations at the same
+                                 * parameters: per-clip combine / LSTM chains / loss tree, parameter gradients summed. */
 } mst_dims;
 
 enum { MST_STAGE_EXTRACT = 1, MST_STAGE_INFO = 2, MST_STAGE_APPLY = 4, MST_STAGE_ALL = 7 };
@@ -70,6 +74,9 @@ int64_t mst_plan_workspace_floats(const mst_plan* p);
  * "bpm_pred","pitched_pred","unpitched_pred","pitched_beats","pitched_bars",... */
 int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t* off, int64_t* goff, int64_t* numel);
 int32_t mst_plan_launch_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
+/* out = {clips, activation floats per clip, scratch floats per clip, offset of the gradient arena}.
+ * Clip k's copy of a named tensor sits k * out[1] floats after clip 0's (mst_plan_tensor offsets). */
+int32_t mst_plan_layout(const mst_plan* p, int64_t out[4]);
 
 /* ---- forward: StyleTransferModel.extract_style / predict_song_info / apply_style / forward
  * (style/model.py:751-793), selected by stage_mask. `pitched` (1,C,R,T,10,56,5) and
@@ -112,7 +119,10 @@ int32_t mst_total_loss_bwd(const float* pitched_pred, const float* pitched_targe
 
 /* ---- one train-model.py loop body (train-model.py:113-126): forward, total loss,
  * backward; gradients accumulate in gparams. Targets are the inputs (auto-encoder), the
- * instrument target is `used` (n_instruments), bpm target a device float. losses may be null. */
+ * instrument target is `used` (n_instruments), bpm target a device float. losses may be null.
+ * With mst_dims.clips = K: `pitched` is (K,C,R,T,10,56,5), `unpitched` (K,1,R,T,10,47,2), `losses`
+ * K x MST_N_LOSSES, the per-clip small inputs sit in each clip's workspace slice, and gparams
+ * receives the SUM over the K clips (= K loop bodies at the same parameters). */
 int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
                             const float* pitched, const float* unpitched, float* losses, mst_stream stream);
 

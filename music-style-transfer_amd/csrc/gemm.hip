@@ -213,17 +213,18 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
 // all small Linears of one dependency level — into a single launch.
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, Bases b) {
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, int blocks_per_clip, Bases b) {
     // A tile | B tile; the final reduce overlays the whole block with one 32x32 partial tile per wave
     constexpr int TILE_F = GEMM_BK * (GEMM_BM + 4), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
     __shared__ float smem[(2 * TILE_F > RED_F) ? 2 * TILE_F : RED_F];
     float (*As)[GEMM_BM + 4] = reinterpret_cast<float (*)[GEMM_BM + 4]>(smem);
     float (*Bs)[GEMM_BN + 4] = reinterpret_cast<float (*)[GEMM_BN + 4]>(smem + TILE_F);
-    // flat 1-D grid: member y owns workgroups [blk_begin, blk_begin + tiles * ksplit)
+    // flat 1-D grid: clip-major; inside a clip's block range member y owns [blk_begin, blk_begin + tiles * ksplit)
+    const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
     int y = 0;
-    while (y + 1 < count && (int)blockIdx.x >= descs[y + 1].blk_begin) ++y;
-    const GemmDesc d = descs[y];                     // by value (scalar loads once): a reference would be re-read after every barrier
-    const int local = blockIdx.x - d.blk_begin;
+    while (y + 1 < count && lb >= descs[y + 1].blk_begin) ++y;
+    const GemmDesc d = descs[clip * count + y];      // by value (scalar loads once): a reference would be re-read after every barrier
+    const int local = lb - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
     const int tile = local % ntile, split = local / ntile;
 #define GEMM_CASE(V, A_, B_, O_, AF_, BF_)                                                          \
@@ -257,9 +258,9 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b, hipStream_t s) {
-    if (count <= 0 || total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(gemm_kernel, dim3(total_blocks), dim3(GEMM_THREADS), 0, s, dev_descs, count, b);
+int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, Bases b, hipStream_t s) {
+    if (members <= 0 || blocks_per_clip <= 0 || clips <= 0) return 0;
+    hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
     return (int)hipGetLastError();
 }
 
@@ -373,17 +374,21 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
     for (int q = 0; q < 4; ++q) {
         const int i = blk.start + q * 256 + threadIdx.x;
         if (i < e.count) {
-            const float* src = b.p[SP_TMP] + e.src + i;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // 4 independent chains keep 4+ loads in flight
-            int sp = 0;
-            for (; sp + 4 <= e.splits; sp += 4) {
-                a0 += src[(int64_t)sp * e.stride];
-                a1 += src[(int64_t)(sp + 1) * e.stride];
-                a2 += src[(int64_t)(sp + 2) * e.stride];
-                a3 += src[(int64_t)(sp + 3) * e.stride];
+            float total = 0.f;
+            for (int r = 0; r < e.reps; ++r) {                  // clips of a batched plan, in order
+                const float* src = b.p[SP_TMP] + e.src + (int64_t)r * e.rep_stride + i;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains keep 4+ loads in flight
+                int sp = 0;
+                for (; sp + 4 <= e.splits; sp += 4) {
+                    a0 += src[(int64_t)sp * e.stride];
+                    a1 += src[(int64_t)(sp + 1) * e.stride];
+                    a2 += src[(int64_t)(sp + 2) * e.stride];
+                    a3 += src[(int64_t)(sp + 3) * e.stride];
+                }
+                for (; sp < e.splits; ++sp) a0 += src[(int64_t)sp * e.stride];
+                total += (a0 + a1) + (a2 + a3);
             }
-            for (; sp < e.splits; ++sp) a0 += src[(int64_t)sp * e.stride];
-            b.p[SP_GPAR][e.dst + i] += (a0 + a1) + (a2 + a3);
+            b.p[SP_GPAR][e.dst + i] += total;
         }
     }
 }

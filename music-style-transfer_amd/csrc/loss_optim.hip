@@ -49,10 +49,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // grid (nblk_p + nblk_u): first nblk_p workgroups reduce the pitched tensor, the rest the unpitched
+// blockIdx.y = clip of a batched plan (per-clip pointer strides in lb; all 0 for a single clip)
 __global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, const float* pt, int64_t np, int nblk_p,
                                                             const float* up, const float* ut, int64_t nu, int nblk_u,
-                                                            float* scratch) {
+                                                            float* scratch, LossBatch lb) {
     __shared__ float red[4][NP_SUMS];
+    {
+        const int64_t k = blockIdx.y;
+        pp += k * lb.ws; pt += k * lb.ext0; up += k * lb.ws; ut += k * lb.ext1; scratch += k * lb.tmp;
+    }
     const bool pitched = (int)blockIdx.x < nblk_p;
     const int blk = pitched ? blockIdx.x : blockIdx.x - nblk_p;
     const int nb = pitched ? nblk_p : nblk_u;
@@ -142,9 +147,14 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
                                                        const float* il, const float* it, int ni,
                                                        const float* mlg, const float* mt,
                                                        const float* bp, const float* bt, int normalize,
-                                                       float* losses, float* saved) {
+                                                       float* losses, float* saved, LossBatch lb) {
     __shared__ float sums[N_TAPE_IN];
     const int tid = threadIdx.x;
+    {
+        const int64_t k = blockIdx.y;
+        scratch += k * lb.tmp; il += k * lb.ws; it += k * lb.ws; mlg += k * lb.ws; mt += k * lb.ws; bp += k * lb.ws;
+        bt += k * lb.ws; losses += k * lb.ws; saved += k * lb.ws;
+    }
     // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; tape inputs 0..6 are the pitched tensor's,
     // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}.  Lanes stride over the per-workgroup partials,
     // then a fixed-order wave reduction (the tail is one 64-lane wave).
@@ -222,8 +232,15 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
                                                        const float* il, const float* it, int ni,
                                                        const float* mlg, const float* mt, const float* bp, const float* bt,
                                                        const float* saved, const float* gl,
-                                                       float* gp, float* gu, float* gi, float* gm, float* gb) {
+                                                       float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb) {
     __shared__ float coef[N_TAPE_IN];
+    {
+        const int64_t k = blockIdx.y;
+        pp += k * lb.ws; pt += k * lb.ext0; up += k * lb.ws; ut += k * lb.ext1;
+        il += k * lb.ws; it += k * lb.ws; mlg += k * lb.ws; mt += k * lb.ws; bp += k * lb.ws; bt += k * lb.ws;
+        saved += k * lb.ws; gl += k * lb.ws;
+        gp += k * lb.grad; gu += k * lb.grad; gi += k * lb.grad; gm += k * lb.grad; gb += k * lb.grad;
+    }
     if (threadIdx.x < N_TAPE_IN) {
         float c = 0.f;
         for (int k = 0; k < MST_N_LOSSES; ++k) {
@@ -286,20 +303,40 @@ static int blocks_for(int64_t n) {
     return (int)b;
 }
 
+int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
+                     const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt, int normalize,
+                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s) {
+    if (!pp || !pt || !il || !it || !mlg || !mt || !bp || !bt || !losses || !saved || !scratch || np <= 0 || lb.clips < 1)
+        return MST_ERR_ARG;
+    const int has_u = (up && ut && nu > 0) ? 1 : 0;
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(nbp + nbu, lb.clips), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
+                       has_u ? nu : (int64_t)0, nbu, scratch, lb);
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1, lb.clips), dim3(64), 0, s, (const float*)scratch, nbp, nbu, has_u, il, it,
+                       ni, mlg, mt, bp, bt, normalize, losses, saved, lb);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
+                     const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
+                     const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
+                     hipStream_t s) {
+    if (!pp || !pt || !saved || !gl || !gp || !gi || !gm || !gb || np <= 0 || lb.clips < 1) return MST_ERR_ARG;
+    const int has_u = (up && ut && gu && nu > 0) ? 1 : 0;
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nbp + nbu + 1, lb.clips), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
+                       has_u ? nu : (int64_t)0, nbu, il, it, ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb, lb);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+static const LossBatch ONE_CLIP = {1, 0, 0, 0, 0, 0};
+
 extern "C" int32_t mst_total_loss_fwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,
                                       int64_t nu, const float* il, const float* it, int32_t ni, const float* mlg,
                                       const float* mt, const float* bp, const float* bt, int32_t normalize,
                                       float* losses, float* saved, float* scratch, mst_stream stream) {
-    if (!pp || !pt || !il || !it || !mlg || !mt || !bp || !bt || !losses || !saved || !scratch || np <= 0)
-        return MST_ERR_ARG;
-    const int has_u = (up && ut && nu > 0) ? 1 : 0;
-    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_partials_kernel, dim3(nbp + nbu), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
-                       has_u ? nu : (int64_t)0, nbu, scratch);
-    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, nbp, nbu, has_u, il, it,
-                       (int)ni, mlg, mt, bp, bt, (int)normalize, losses, saved);
-    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+    return loss_fwd_batched(pp, pt, np, up, ut, nu, il, it, (int)ni, mlg, mt, bp, bt, (int)normalize, losses, saved, scratch,
+                            ONE_CLIP, (hipStream_t)stream);
 }
 
 extern "C" int32_t mst_total_loss_bwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,
@@ -307,12 +344,8 @@ extern "C" int32_t mst_total_loss_bwd(const float* pp, const float* pt, int64_t 
                                       const float* mt, const float* bp, const float* bt, const float* saved,
                                       const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb,
                                       mst_stream stream) {
-    if (!pp || !pt || !saved || !gl || !gp || !gi || !gm || !gb || np <= 0) return MST_ERR_ARG;
-    const int has_u = (up && ut && gu && nu > 0) ? 1 : 0;
-    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nbp + nbu + 1), dim3(256), 0, (hipStream_t)stream, pp, pt, np, nbp, up, ut,
-                       has_u ? nu : (int64_t)0, nbu, il, it, (int)ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb);
-    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+    return loss_bwd_batched(pp, pt, np, up, ut, nu, il, it, (int)ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb, ONE_CLIP,
+                            (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ Adam + StepLR

@@ -57,9 +57,6 @@ struct Operand {
     int64_t si, sj;      // DENSE: val = base[off + i*si + j*sj], (i,j) = (m,k) for A, (k,n) for B
     int32_t ones_at;     // second index == ones_at -> 1.0f (bias-gradient column); -1 = none
     int32_t kfast;       // tile loader walks the k index fastest (coalescing hint)
-    // CAT (first index = row in the 4-D row space, second = concatenated feature)
-    int32_t nseg, d1, d2, d3;
-    Seg seg[MAX_SEG];
     // ACTGRAD: val(row,j) = dY[row*ld+j] * act'(Y[row*ld+j]); transposed: first index is j
     int32_t space2, ld, act, transposed;
     int64_t off2;
@@ -145,7 +142,8 @@ struct NotesDesc {
 };
 
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
-struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; };
+// (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
+struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; };
 struct SlabBlock { int32_t entry, start; };   // one workgroup's 1024-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)
@@ -170,17 +168,28 @@ Sizes mst_sizes(const mst_dims& d);
 enum { GV_LIN_FWD, GV_LIN_FWD_PERM, GV_LIN_DW, GV_LIN_DW_PERM, GV_LIN_DA, GV_CONV_FWD, GV_CONV_DW, GV_HH_DW };
 int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipStream_t s);
 int gemm_variant(const GemmDesc& g);
-int launch_gemm(const GemmDesc* dev_descs, int count, int total_blocks, Bases b, hipStream_t s);
+// descs = clips x members (clip-major); every clip's copy of a member has the same blk_begin inside the clip's block range
+int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, Bases b, hipStream_t s);
 int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s);
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
 int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
-int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
-int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
-int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
-int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, Bases b, hipStream_t s);
+// `count` descriptors of identical shape (the clips of a batched plan), blockIdx.y = descriptor
+int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+// per-clip strides of a batched loss evaluation (all 0 for the stand-alone single-clip entry points)
+struct LossBatch { int32_t clips; int64_t ws, grad, tmp, ext0, ext1; };
+int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
+                     const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt, int normalize,
+                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s);
+int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
+                     const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
+                     const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
+                     hipStream_t s);
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s);
 bool notes_widths_supported(int W, int CW, int ML);
 

@@ -20,7 +20,7 @@ __device__ __forceinline__ float dlrelu(float y) { return y > 0.f ? 1.f : LEAKY;
 // ============================================================================ MelodyEncoder
 template <int W, int CW>
 __global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
-    const NotesDesc d = *dp;
+    const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = W + CW;
     __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL], bl_s[W];
     __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __re
 
 template <int W, int CW>
 __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
-    const NotesDesc d = *dp;
+    const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = W + CW;
     constexpr int R_WC = 0, R_BC = CW * NPF, R_WL = R_BC + CW, R_BL = R_WL + W * KL, NW = R_BL + W;
     static_assert(NW <= 256 && (NOCT + NDEG) * W <= 256, "role count exceeds the workgroup");
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
 #define PSA_HW 30
 template <int ML>
 __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
-    const NotesDesc d = *dp;
+    const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
     __shared__ float w_s[NPF * KL], b_s[NPF];
     __shared__ float lo_s[NOCT * PSA_HW], ld_s[NDEG * PSA_HW];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
 
 template <int ML>
 __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
-    const NotesDesc d = *dp;
+    const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
     constexpr int NW = NPF * KL + NPF;                 // linear.weight (5 x KL) then linear.bias (5)
     constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW;
@@ -326,21 +326,21 @@ bool notes_widths_supported(int W, int CW, int ML) {
     else if (h.ML == 14) hipLaunchKernelGGL((KERN<14>), GRID, BLOCK, 0, s, dev, b);                   \
     else return MST_ERR_UNSUPPORTED;
 
-int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
     int P = h.C * h.Q;
-    ME_DISPATCH(me_notes_fwd_kernel, dim3(P < 2048 ? P : 2048), dim3(256));
+    ME_DISPATCH(me_notes_fwd_kernel, dim3(P < 2048 ? P : 2048, count), dim3(256));
     return (int)hipGetLastError();
 }
-int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
-    ME_DISPATCH(me_notes_bwd_kernel, dim3(h.nblk), dim3(256));
+int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
+    ME_DISPATCH(me_notes_bwd_kernel, dim3(h.nblk, count), dim3(256));
     return (int)hipGetLastError();
 }
-int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
+int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
     int QF = h.Q * NF;
-    PSA_DISPATCH(psa_notes_fwd_kernel, dim3(QF < 4096 ? QF : 4096), dim3(64));
+    PSA_DISPATCH(psa_notes_fwd_kernel, dim3(QF < 4096 ? QF : 4096, count), dim3(64));
     return (int)hipGetLastError();
 }
-int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, Bases b, hipStream_t s) {
-    PSA_DISPATCH(psa_notes_bwd_kernel, dim3(h.nblk), dim3(256));
+int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
+    PSA_DISPATCH(psa_notes_bwd_kernel, dim3(h.nblk, count), dim3(256));
     return (int)hipGetLastError();
 }

@@ -4,7 +4,12 @@
 // reverse".  All descriptors are uploaded once at plan creation; running a plan only enqueues
 // kernels on the caller's stream (no allocation, no host sync => hipGraph-capturable).
 //
-// Workspace layout (floats):  [ activations | gradients (same offsets) | scratch ]
+// Workspace layout (floats):  [ activations | gradients (same offsets) | scratch ], each arena holding
+// one slice per clip.  A plan for K clips (mst_dims.clips) is the one-clip plan with every launch
+// widened: at schedule time each descriptor is replicated K times with its workspace / note-tensor
+// offsets relocated to clip k's slices, so the launch count stays that of one clip while every
+// launch carries K times the work.  Clips never mix: `combine`, the loss tree and the LSTM chains are
+// per clip (B = 1 in the reference); only the parameter gradients are summed over clips, in order.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -158,7 +163,7 @@ static void build_params(const mst_dims& d, const Sizes& z, ParamTable& t) {
 static bool dims_ok(const mst_dims* d) {
     return d && d->C >= 1 && d->C <= COMBINE_MAXC && d->R >= 1 && d->T >= 1 && d->beat >= 1 && d->bar >= 2 &&
            d->bar % 2 == 0 && d->nrf >= 1 && d->style >= 1 && d->melody >= 1 && d->rhythm >= 1 && d->instr >= 1 &&
-           d->n_instruments >= 1;
+           d->n_instruments >= 1 && d->clips >= 0 && d->clips <= 4096;
 }
 
 extern "C" int32_t mst_param_count(const mst_dims* d) {
@@ -208,12 +213,13 @@ struct mst_plan {
     std::vector<Step> sched_all[2];    // stage-agnostic merging, used when all stages run together
     const std::vector<Step>& list(int mask, int backward) const { return mask == MST_STAGE_ALL ? sched_all[backward ? 1 : 0] : sched[backward ? 1 : 0]; }
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
-    std::vector<CombineDesc> s_combines;
+    std::vector<CombineDesc> s_combines; std::vector<NotesDesc> s_notes;
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
     GemmDesc* d_gemms = nullptr; GatherDesc* d_gathers = nullptr; SegRedDesc* d_segreds = nullptr; LstmDesc* d_lstms = nullptr;
-    CombineDesc* d_combines = nullptr; NotesDesc* d_notes = nullptr; SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
+    CombineDesc* d_combines = nullptr; NotesDesc* d_notes = nullptr;     // d_notes: the scheduled (per-clip) copies, s_notes
+    SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabBlock> slab_blocks[3]; SlabBlock* d_slab_blocks[3] = {nullptr, nullptr, nullptr};
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     int err = 0;
@@ -224,6 +230,53 @@ struct mst_plan {
 
     int P() const { return d.C * d.R * d.T; }
     int Q() const { return d.R * d.T; }
+    int K() const { return d.clips > 1 ? d.clips : 1; }
+    int64_t ext0_stride() const { return (int64_t)P() * NF * NPN * NPF; }
+    int64_t ext1_stride() const { return (int64_t)Q() * NF * NUN * NUF; }
+    // offset of clip k's slice of `space` relative to clip 0's
+    int64_t shift(int space, int k) const {
+        switch (space) {
+        case SP_WS: case SP_GRAD: return (int64_t)k * act_top;
+        case SP_TMP: return (int64_t)k * tmp_top;
+        case SP_EXT0: return (int64_t)k * ext0_stride();
+        case SP_EXT1: return (int64_t)k * ext1_stride();
+        default: return 0;                                  // parameters are shared
+        }
+    }
+    GemmDesc reloc(GemmDesc g, int k) const {
+        for (Operand* o : {&g.A, &g.B}) {
+            o->off += shift(o->space, k);
+            if (o->kind == OPK_ACTGRAD || o->kind == OPK_CONVGRAD) o->off2 += shift(o->space2, k);
+        }
+        g.out.off += shift(g.out.space, k);
+        return g;
+    }
+    GatherDesc reloc(GatherDesc g, int k) const {
+        g.out_off += shift(SP_WS, k);
+        for (int i = 0; i < g.nseg; ++i) g.seg[i].off += shift(g.seg[i].space, k);
+        return g;
+    }
+    SegRedDesc reloc(SegRedDesc r, int k) const {
+        r.src_off += shift(SP_GRAD, k); r.dst_off += shift(SP_GRAD, k); r.part_off += shift(SP_TMP, k);
+        return r;
+    }
+    LstmDesc reloc(LstmDesc l, int k) const {           // whht (W_hh transposed) is shared: parameters only
+        const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
+        l.zx_off += a; l.out_off += a; l.gout_off += a; l.gzx_off += a;
+        l.gates_off += t; l.c_off += t; l.hprev_off += t; l.tc_off += t;
+        return l;
+    }
+    CombineDesc reloc(CombineDesc c, int k) const {
+        const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
+        c.x_off += a; c.out_off += a; c.gx_off += a; c.gout_off += a; c.stats_off += t; c.part_off += t;
+        return c;
+    }
+    NotesDesc reloc(NotesDesc n, int k) const {
+        const int64_t a = shift(SP_WS, k);
+        n.oct_off += a; n.deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
+        n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += shift(SP_TMP, k);
+        return n;
+    }
 
     static int64_t align(int64_t n) { return (n + 63) / 64 * 64; }
     T newT(int rows, int cols, const char* name = nullptr) {
@@ -813,41 +866,59 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                                    s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
             Step m = s0; m.count = 0;
             std::vector<Acc> mac;
+            const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
+            const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B;
+            const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B;
             if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
             else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
             else if (s0.kind == K_SEGRED) m.first = (int)s_segreds.size();
-            else if (s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B) m.first = (int)s_lstms.size();
-            else if (s0.kind == K_COMB_F || s0.kind == K_COMB_B) m.first = (int)s_combines.size();
+            else if (is_lstm) m.first = (int)s_lstms.size();
+            else if (is_comb) m.first = (int)s_combines.size();
+            else if (is_notes) m.first = (int)s_notes.size();
+            std::vector<int> members;                       // indices into the per-kind descriptor vectors (one clip)
             for (int j = i; j < n; ++j) {
                 if (done[j] || level[j] != lv) continue;
                 const Step& s = seq[j];
                 if (s.kind != s0.kind || (!across_stages && s.stage != s0.stage)) continue;
                 // LSTM launches come in a register-resident (H <= 64) and an L2 flavour
-                if ((s.kind == K_LSTM_F || s.kind == K_LSTM_B || s.kind == K_LSTM_T) && ((s.b > 64) != (s0.b > 64))) continue;
+                if (is_lstm && ((s.b > 64) != (s0.b > 64))) continue;
                 if (j != i && !mergeable) continue;
                 done[j] = 1;
                 mac.insert(mac.end(), acc[j].begin(), acc[j].end());
-                for (int q = 0; q < s.count; ++q) {
-                    if (s.kind == K_GEMM) { GemmDesc g = gemms[s.first + q]; g.variant = gemm_variant(g);
-                        { const int kr = (g.K + g.ksplit - 1) / g.ksplit; g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2); } if (g.variant < 0) err = MST_ERR_UNSUPPORTED; s_gemms.push_back(g); }
-                    else if (s.kind == K_GATHER) s_gathers.push_back(gathers[s.first + q]);
-                    else if (s.kind == K_SEGRED) s_segreds.push_back(segreds[s.first + q]);
-                    else if (s.kind == K_LSTM_T || s.kind == K_LSTM_F || s.kind == K_LSTM_B) s_lstms.push_back(lstms[s.first + q]);
-                    else if (s.kind == K_COMB_F || s.kind == K_COMB_B) s_combines.push_back(combines[s.first + q]);
-                }
-                m.count += s.count;
+                for (int q = 0; q < s.count; ++q) members.push_back(s.first + q);
                 m.stage |= s.stage;
                 if (s.a > m.a) m.a = s.a;
                 if (s.b > m.b) m.b = s.b;
             }
-            if (m.kind == K_GEMM) {      // flat grid: concatenate every member's (tile, k-split) workgroups
-                int total = 0;
-                for (int q = 0; q < m.count; ++q) {
-                    GemmDesc& g = s_gemms[m.first + q];
-                    g.blk_begin = total;
-                    total += tiles(g.M, g.N) * g.ksplit;
+            // clip-major replication: clip k's copy of every member, relocated to clip k's workspace slices.
+            // The W_hh transpose reads parameters only, so it runs once for all clips.
+            const int copies = s0.kind == K_LSTM_T ? 1 : K();
+            for (int k = 0; k < copies; ++k) {
+                for (int idx : members) {
+                    if (s0.kind == K_GEMM) {
+                        GemmDesc g = reloc(gemms[idx], k); g.variant = gemm_variant(g);
+                        const int kr = (g.K + g.ksplit - 1) / g.ksplit;
+                        g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2);
+                        if (g.variant < 0) err = MST_ERR_UNSUPPORTED;
+                        s_gemms.push_back(g);
+                    }
+                    else if (s0.kind == K_GATHER) s_gathers.push_back(reloc(gathers[idx], k));
+                    else if (s0.kind == K_SEGRED) s_segreds.push_back(reloc(segreds[idx], k));
+                    else if (is_lstm) s_lstms.push_back(reloc(lstms[idx], k));
+                    else if (is_comb) s_combines.push_back(reloc(combines[idx], k));
+                    else if (is_notes) s_notes.push_back(reloc(notes[idx], k));
                 }
-                m.a = total; m.b = 0;
+            }
+            m.count = (int)members.size() * copies;
+            if (m.kind == K_GEMM) {      // flat grid: a clip's block range concatenates its members' (tile, k-split) workgroups
+                const int nm = (int)members.size();
+                int total = 0;
+                for (int q = 0; q < nm; ++q) {
+                    const GemmDesc& g0 = s_gemms[m.first + q];
+                    for (int k = 0; k < copies; ++k) s_gemms[m.first + k * nm + q].blk_begin = total;
+                    total += tiles(g0.M, g0.N) * g0.ksplit;
+                }
+                m.a = total; m.b = nm;        // blocks per clip, members per clip
             }
             out.push_back(m);
             macc.push_back(std::move(mac));
@@ -916,8 +987,9 @@ static int up(const std::vector<D>& v, D** dev) {
 int mst_plan::upload() {
     int e = 0;
     e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
-    e |= up(s_combines, &d_combines); e |= up(notes, &d_notes);
+    e |= up(s_combines, &d_combines); e |= up(s_notes, &d_notes);
     for (int s = 0; s < 3; ++s) {
+        for (auto& ent : slabs[s]) { ent.reps = K(); ent.rep_stride = tmp_top; }
         e |= up(slabs[s], &d_slabs[s]);
         for (size_t i = 0; i < slabs[s].size(); ++i)
             for (int st = 0; st < slabs[s][i].count; st += 1024) slab_blocks[s].push_back(SlabBlock{(int)i, st});
@@ -931,6 +1003,7 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
     mst_plan* p = new mst_plan();
     p->d = *d; p->z = mst_sizes(*d);
+    if (p->d.clips < 1) p->d.clips = 1;
     build_params(*d, p->z, p->pt);
     p->build();
     if (!p->err) p->schedule();
@@ -953,14 +1026,20 @@ extern "C" void mst_plan_destroy(mst_plan* p) {
     delete p;
 }
 
-extern "C" int64_t mst_plan_workspace_floats(const mst_plan* p) { return p ? 2 * p->act_top + p->tmp_top : MST_ERR_ARG; }
+extern "C" int64_t mst_plan_workspace_floats(const mst_plan* p) { return p ? (int64_t)p->K() * (2 * p->act_top + p->tmp_top) : MST_ERR_ARG; }
+
+extern "C" int32_t mst_plan_layout(const mst_plan* p, int64_t out[4]) {
+    if (!p || !out) return MST_ERR_ARG;
+    out[0] = p->K(); out[1] = p->act_top; out[2] = p->tmp_top; out[3] = (int64_t)p->K() * p->act_top;
+    return MST_OK;
+}
 
 extern "C" int32_t mst_plan_tensor(const mst_plan* p, const char* name, int64_t* off, int64_t* goff, int64_t* numel) {
     if (!p || !name) return MST_ERR_ARG;
     auto it = p->named.find(name);
     if (it == p->named.end()) return MST_ERR_ARG;
     if (off) *off = it->second.off;
-    if (goff) *goff = p->act_top + it->second.off;
+    if (goff) *goff = (int64_t)p->K() * p->act_top + it->second.off;
     if (numel) *numel = (int64_t)it->second.rows * it->second.cols;
     return MST_OK;
 }
@@ -981,13 +1060,13 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
     Bases b;
     b.p[SP_WS] = ws; b.p[SP_PAR] = const_cast<float*>(params); b.p[SP_GPAR] = gparams;
     b.p[SP_EXT0] = const_cast<float*>(pitched); b.p[SP_EXT1] = const_cast<float*>(unpitched);
-    b.p[SP_GRAD] = ws + p->act_top; b.p[SP_TMP] = ws + 2 * p->act_top;
+    b.p[SP_GRAD] = ws + (int64_t)p->K() * p->act_top; b.p[SP_TMP] = ws + 2 * (int64_t)p->K() * p->act_top;
     return b;
 }
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.count, s.a, b, st);
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.b, s.a, s.count / s.b, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
@@ -995,10 +1074,10 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, b, st);
     case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, b, st);
-    case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
-    case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->notes[s.first], b, st);
-    case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->notes[s.first], b, st);
-    case K_PSA_B: return launch_psa_notes_bwd(p->d_notes + s.first, p->notes[s.first], b, st);
+    case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
+    case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
+    case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
+    case K_PSA_B: return launch_psa_notes_bwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     }
     return MST_ERR_ARG;
 }
@@ -1057,13 +1136,24 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
 extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
     if (!p || !ws) return MST_ERR_ARG;
     // the stage regions are allocated back to back: clear runs of selected stages with one memset each
+    float* g = ws + (int64_t)p->K() * p->act_top;
     for (int s = 0; s < 3;) {
         if (!((mask >> s) & 1)) { ++s; continue; }
         int e = s;
         while (e + 1 < 3 && ((mask >> (e + 1)) & 1) && p->stage_begin[e + 1] == p->stage_end[e]) ++e;
         const int64_t n = p->stage_end[e] - p->stage_begin[s];
-        if (n > 0 && hipMemsetAsync(ws + p->act_top + p->stage_begin[s], 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return MST_ERR_LAUNCH;
+        if (n > 0) {
+            if (s == 0 && e == 2) {
+                // every stage of every clip: one memset from clip 0's first slot to the last clip's last slot (the input /
+                // loss slots of the gradient arena that this also covers are never read)
+                const int64_t span = (int64_t)(p->K() - 1) * p->act_top + n;
+                if (hipMemsetAsync(g + p->stage_begin[s], 0, span * sizeof(float), (hipStream_t)stream) != hipSuccess) return MST_ERR_LAUNCH;
+            } else {
+                for (int k = 0; k < p->K(); ++k)
+                    if (hipMemsetAsync(g + (int64_t)k * p->act_top + p->stage_begin[s], 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess)
+                        return MST_ERR_LAUNCH;
+            }
+        }
         s = e + 1;
     }
     return MST_OK;
@@ -1086,9 +1176,14 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     return MST_OK;
 }
 
-__global__ void onehot_kernel(float* p, int n, int hot) {
+__global__ void onehot_kernel(float* p, int n, int hot, int64_t clip_stride) {
     const int i = threadIdx.x;
-    if (i < n) p[i] = i == hot ? 1.f : 0.f;
+    if (i < n) p[(int64_t)blockIdx.x * clip_stride + i] = i == hot ? 1.f : 0.f;
+}
+
+__global__ void collect_kernel(float* dst, const float* src, int n, int64_t clip_stride) {
+    const int i = threadIdx.x;
+    if (i < n) dst[(int64_t)blockIdx.x * n + i] = src[(int64_t)blockIdx.x * clip_stride + i];
 }
 
 extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
@@ -1100,27 +1195,29 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     e = mst_forward(p, MST_STAGE_ALL, params, ws, pitched, unpitched, stream);
     if (e) return e;
     const bool U = p->d.has_unpitched != 0;
-    float* g = ws + p->act_top;
+    const int K = p->K();
+    float* g = ws + (int64_t)K * p->act_top;
     auto at = [&](const char* n) { return p->named.at(n).off; };
     const int64_t np = (int64_t)p->P() * NF * NPN, nu = U ? (int64_t)p->Q() * NF * NUN : 0;
-    float* lscratch = ws + 2 * p->act_top + p->loss_scratch;
-    e = mst_total_loss_fwd(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
-                           nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
-                           ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), 1, ws + p->t_losses.off,
-                           ws + p->t_saved.off, lscratch, stream);
+    float* lscratch = ws + 2 * (int64_t)K * p->act_top + p->loss_scratch;
+    const LossBatch lb = {K, p->act_top, p->act_top, p->tmp_top, p->ext0_stride(), p->ext1_stride()};
+    e = loss_fwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
+                         nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
+                         ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), 1, ws + p->t_losses.off,
+                         ws + p->t_saved.off, lscratch, lb, st);
     if (e) return e;
-    hipLaunchKernelGGL(onehot_kernel, dim3(1), dim3(64), 0, st, ws + p->t_gl.off, (int)MST_N_LOSSES, (int)MST_L_TOTAL);
-    e = mst_total_loss_bwd(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
-                           nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
-                           ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off,
-                           ws + p->t_gl.off, g + at("pitched_pred"), U ? g + at("unpitched_pred") : nullptr,
-                           g + at("instruments_pred"), g + at("mode_pred"), g + at("bpm_pred"), stream);
+    hipLaunchKernelGGL(onehot_kernel, dim3(K), dim3(64), 0, st, ws + p->t_gl.off, (int)MST_N_LOSSES, (int)MST_L_TOTAL, p->act_top);
+    e = loss_bwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
+                         nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
+                         ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off,
+                         ws + p->t_gl.off, g + at("pitched_pred"), U ? g + at("unpitched_pred") : nullptr,
+                         g + at("instruments_pred"), g + at("mode_pred"), g + at("bpm_pred"), lb, st);
     if (e) return e;
     e = mst_backward(p, MST_STAGE_ALL, params, gparams, ws, pitched, unpitched, stream);
     if (e) return e;
-    if (losses && hipMemcpyAsync(losses, ws + p->t_losses.off, MST_N_LOSSES * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return MST_ERR_LAUNCH;
-    return MST_OK;
+    if (losses) hipLaunchKernelGGL(collect_kernel, dim3(K), dim3(64), 0, st, losses, (const float*)(ws + p->t_losses.off),
+                                   (int)MST_N_LOSSES, p->act_top);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
 
@@ -1154,28 +1251,29 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
             b += 4.0 * ((double)l.B * l.S * 11.0 * l.H + 4.0 * l.H * l.H);
         }
         break;
-    case K_COMB_F: case K_COMB_B: {
-        const CombineDesc& c = p->s_combines[s.first];
-        const double n = (double)c.rows * c.cols;
-        f = n * c.Cn * (s.kind == K_COMB_F ? 4.0 : 8.0);
-        b = 4.0 * n * (s.kind == K_COMB_F ? 2.0 * c.Cn + 1 : 4.0 * c.Cn + 2);
+    case K_COMB_F: case K_COMB_B:
+        for (int i = 0; i < s.count; ++i) {
+            const CombineDesc& c = p->s_combines[s.first + i];
+            const double n = (double)c.rows * c.cols;
+            f += n * c.Cn * (s.kind == K_COMB_F ? 4.0 : 8.0);
+            b += 4.0 * n * (s.kind == K_COMB_F ? 2.0 * c.Cn + 1 : 4.0 * c.Cn + 2);
+        }
         break;
-    }
     case K_ME_F: case K_ME_B: {
-        const NotesDesc& n = p->notes[s.first];
-        const double pos = (double)n.C * n.Q * NF * NPN;
+        const NotesDesc& n = p->s_notes[s.first];
+        const double pos = (double)n.C * n.Q * NF * NPN * s.count;
         const double per = 2.0 * n.W + 2.0 * n.CW * NPF + 2.0 * n.W * (n.W + n.CW);
         f = pos * per * (s.kind == K_ME_F ? 1.0 : 3.0);
         b = 4.0 * pos * (NPF + n.W * (s.kind == K_ME_F ? 1.0 : 2.0));
         break;
     }
     case K_PSA_F: case K_PSA_B: {
-        const NotesDesc& n = p->notes[s.first];
-        const double pos = (double)n.C * n.Q * NF * NPN;
+        const NotesDesc& n = p->s_notes[s.first];
+        const double pos = (double)n.C * n.Q * NF * NPN * s.count;
         const double per = 2.0 * 30 + 2.0 * NPF * (30 + n.ML);
         f = pos * per * (s.kind == K_PSA_F ? 1.0 : 3.0);
-        b = 4.0 * (pos * NPF * (s.kind == K_PSA_F ? 1.0 : 2.0) + (double)n.C * n.Q * NF * 450 * (s.kind == K_PSA_F ? 1.0 : 2.0) +
-                   (double)n.Q * NF * NPN * n.ML * (s.kind == K_PSA_F ? 1.0 : 2.0));
+        b = 4.0 * (pos * NPF * (s.kind == K_PSA_F ? 1.0 : 2.0) + (double)s.count * n.C * n.Q * NF * 450 * (s.kind == K_PSA_F ? 1.0 : 2.0) +
+                   (double)s.count * n.Q * NF * NPN * n.ML * (s.kind == K_PSA_F ? 1.0 : 2.0));
         break;
     }
     }

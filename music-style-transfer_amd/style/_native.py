@@ -31,7 +31,7 @@ class MstError(RuntimeError):
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('C', 'R', 'T', 'beat', 'bar', 'nrf', 'style', 'melody', 'rhythm',
-                                         'instr', 'n_instruments', 'has_unpitched')]
+                                         'instr', 'n_instruments', 'has_unpitched', 'clips')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -48,6 +48,7 @@ _SIGS = {
     'mst_plan_workspace_floats': (C.c_int64, [_P]),
     'mst_plan_tensor': (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mst_plan_launch_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    'mst_plan_layout': (C.c_int32, [_P, C.POINTER(C.c_int64 * 4)]),
     'mst_forward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     'mst_backward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     'mst_zero_grads': (C.c_int32, [_P, C.c_int32, _P, _P]),
@@ -139,6 +140,9 @@ class Plan:
         n = self.lib.mst_plan_workspace_floats(self.handle)
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._slots = {}
+        lay = (C.c_int64 * 4)()
+        check(self.lib.mst_plan_layout(self.handle, C.byref(lay)), 'mst_plan_layout')
+        self.clips, self.clip_stride = int(lay[0]), int(lay[1])
 
     def __del__(self):
         try:
@@ -160,20 +164,22 @@ class Plan:
         """A fresh workspace for this plan (one per in-flight forward whose backward is still pending)."""
         return torch.zeros_like(self.ws)
 
-    def view(self, name, shape=None, ws=None):
+    def view(self, name, shape=None, ws=None, clip=0):
         off, _, n = self.slot(name)
+        off += clip * self.clip_stride
         t = (self.ws if ws is None else ws)[off:off + n]
         return t.view(*shape) if shape is not None else t
 
-    def grad(self, name, shape=None, ws=None):
+    def grad(self, name, shape=None, ws=None, clip=0):
         _, goff, n = self.slot(name)
+        goff += clip * self.clip_stride
         t = (self.ws if ws is None else ws)[goff:goff + n]
         return t.view(*shape) if shape is not None else t
 
-    def set_inputs(self, mode=None, bpm=None, instr=None, used=None, bpm_target=None, ws=None):
+    def set_inputs(self, mode=None, bpm=None, instr=None, used=None, bpm_target=None, ws=None, clip=0):
         for name, t in (('mode', mode), ('bpm', bpm), ('instr', instr), ('used_instruments', used), ('bpm_target', bpm_target)):
             if t is not None:
-                self.view(name, ws=ws).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
+                self.view(name, ws=ws, clip=clip).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
 
     def launch_count(self, mask=STAGE_ALL, backward=False):
         return self.lib.mst_plan_launch_count(self.handle, mask, int(backward))

@@ -137,3 +137,52 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
         plan.train_iteration(params, g2, xp, xu, losses)
         assert torch.equal(g2, gparams)
     return e, worst
+
+
+def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True):
+    """K different clips in ONE plan (mst_dims.clips = K) against (a) the oracle run clip by clip with
+    gradients accumulating like train-model.py:126 and (b) the product's own one-clip plan run K times:
+    per-clip activations and losses are bit-identical, and so is the summed gradient (same order)."""
+    dims1 = make_dims(widths, C, R, T, unp)
+    dimsK = make_dims(widths, C, R, T, unp, clips=K)
+    flat, named, table = random_params(native, dims1, seed)
+    clips = [synth_clip(10 + k, C, R, T, unp, density=density) for k in range(K)]
+    params = flat.to(device)
+    planK = nat.Plan(native, dimsK, device)
+    assert planK.clips == K
+    for k, clip in enumerate(clips):
+        planK.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
+                         used=clip['used_instruments'], bpm_target=float(clip['bpm_int']), clip=k)
+    xp = torch.cat([c['pitched'] for c in clips]).contiguous().to(device)
+    xu = torch.cat([c['unpitched'] for c in clips]).contiguous().to(device) if unp else None
+    gK = torch.zeros_like(params)
+    lossesK = torch.zeros(K, nat.N_LOSSES, device=device)
+    planK.train_iteration(params, gK, xp, xu, lossesK)
+    # (b) one-clip plan, K sequential iterations
+    plan1 = nat.Plan(native, dims1, device)
+    g1 = torch.zeros_like(params)
+    losses1 = torch.zeros(nat.N_LOSSES, device=device)
+    names = ['style', 'melody', 'rhythm', 'pitched_pred', 'instruments_pred', 'mode_pred', 'bpm_pred'] + (['unpitched_pred'] if unp else [])
+    for k, clip in enumerate(clips):
+        set_clip(plan1, clip)
+        a, b = dev_clip(clip, device)
+        plan1.train_iteration(params, g1, a, b, losses1)
+        for name in names:
+            assert torch.equal(planK.view(name, clip=k), plan1.view(name)), (name, k)
+        assert torch.equal(lossesK[k].nan_to_num(-1.), losses1.nan_to_num(-1.)), k
+    assert torch.equal(gK, g1)
+    if not check_oracle:
+        return
+    # (a) oracle, clip by clip, grads accumulate
+    for k, clip in enumerate(clips):
+        (info, xp_ref, xu_ref), ref_losses = so.iteration(named, clip)
+        assert rel(planK.view('pitched_pred', clip=k).cpu().numpy(), xp_ref.detach().numpy()) < TOL, k
+        assert rel(planK.view('instruments_pred', clip=k).cpu().numpy(), info[0].detach().numpy()) < TOL, k
+        lc = lossesK[k].cpu()
+        for i, key in enumerate(nat.LOSS_KEYS):
+            if key in ref_losses:
+                assert abs(float(lc[i]) - ref_losses[key]) < 5e-5, (k, key)
+    gref = torch.cat([(named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])).reshape(-1)
+                      for n, _, _ in table])
+    e = rel(gK.cpu().numpy(), gref.numpy())
+    assert e < TOL, ('summed gradients', e)

@@ -34,11 +34,11 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def make_dims(widths, C, R, T, unpitched, instr=51, n_instruments=41):
+def make_dims(widths, C, R, T, unpitched, instr=51, n_instruments=41, clips=1):
     from style._native import Dims
     return Dims(C=C, R=R, T=T, beat=widths['beat'], bar=widths['bar'], nrf=widths['nrf'], style=widths['style'],
                 melody=widths['melody'], rhythm=widths['rhythm'], instr=instr, n_instruments=n_instruments,
-                has_unpitched=int(unpitched))
+                has_unpitched=int(unpitched), clips=clips)
 
 
 def flat_from_named(native, dims, named):

@@ -50,3 +50,18 @@ def test_dataflow_lanes_opt_in_parity(native, monkeypatch):
     # MST_LANES > 1 spreads independent launches over internal side streams with event edges (experimental)
     monkeypatch.setenv('MST_LANES', '4')
     pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 3, True, check_bitwise=True)
+
+
+@pytest.mark.parametrize('C,R,T,unp,K', [(2, 2, 2, True, 3), (1, 3, 1, False, 2)])
+def test_batched_clips_small(native, C, R, T, unp, K):
+    pc.batch_case(native, torch.device('cuda:0'), pc.SMALL, C, R, T, unp, K)
+
+
+def test_batched_clips_full_widths(native):
+    # BASELINE.json configs[2] in miniature: 5 different clips in one plan, every launch carrying all of them
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, 5)
+
+
+def test_batched_64_bench_clips_equal_sequential(native):
+    # BASELINE.json configs[2] at full size: 64 x (C=4, R=16, T=4) clips in one plan == 64 one-clip iterations, bit for bit
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, 64, check_oracle=False)

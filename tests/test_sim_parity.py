@@ -35,3 +35,8 @@ def test_empty_clip_has_finite_losses():
     losses = torch.zeros(nat.N_LOSSES)
     plan.train_iteration(flat, g, torch.zeros(1, 1, 2, 2, 10, 56, 5), None, losses)
     assert torch.isfinite(plan.view('pitched_pred')).all()
+
+
+@pytest.mark.parametrize('C,R,T,unp,K', [(2, 2, 2, True, 3), (1, 3, 1, False, 2)])
+def test_batched_clips_equal_sequential_iterations(C, R, T, unp, K):
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, C, R, T, unp, K)
