@@ -209,6 +209,135 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     }
 }
 
+// ---- throughput flavour: f32 MFMA -----------------------------------------------------------
+// Batched plans (many clips per launch) are FLOP-bound, not latency-bound, so their GEMMs run on the
+// matrix cores: v_mfma_f32_32x32x2_f32 is exact f32 (bit-for-bit a k-ordered fmaf chain) at the
+// chip's f32 peak.  64x64 output tile per 256-lane workgroup, one 32x32 MFMA tile per wave, 32-deep
+// k-tile staged k-major in LDS by the same branch-free accessor loaders as above (so every operand
+// kind / epilogue of the model is covered), next k-tile prefetched into registers under the MFMAs.
+// Fragment maps (cdna_hip_programming.md): lane l feeds A[row = l&31][k = l>>5], B[k = l>>5][col = l&31];
+// accumulator register r of lane l is C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+#define MF_BM 64
+#define MF_BN 64
+#define MF_KD 32
+#define MF_THREADS 256
+typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int AK, int BKIND, int OK, int AKF, int BKF>
+__device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
+                                               float (*As)[MF_BM + 4], float (*Bs)[MF_BN + 4]) {
+    const int tid = threadIdx.x;
+    const int M = d.M, N = d.N;
+    const int tiles_n = (N + MF_BN - 1) / MF_BN;
+    const gcptr baseA = (gcptr)(b.p[d.A.space] + d.A.off);
+    const gcptr baseA2 = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
+    const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
+    kchunk = (kchunk + MF_KD - 1) / MF_KD * MF_KD;
+    const int k0 = split * kchunk;
+    const int k1 = min(d.K, k0 + kchunk);
+    const int wv = tid >> 6, lane = tid & 63;
+    const int wm = wv >> 1, wn = wv & 1;             // this wave's 32x32 quadrant of the 64x64 tile
+    const int a_act = (AK == OPK_ACTGRAD) ? d.A.act : ACT_LEAKY;
+    const int a_tr = d.A.transposed;
+    const int b_ones = (BKIND == OPK_DENSE || BKIND == OPK_IM2COL) ? d.B.ones_at : -1;
+    const bool live = (tm * MF_BM + wm * 32 < M) & (tn * MF_BN + wn * 32 < N);    // wave-uniform
+    mf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int NT = MF_THREADS;
+    constexpr int NL = MF_BM * MF_KD / NT;           // 8 tile elements per lane and operand
+    float va[NL], ya[NL], vb[NL];
+#define A_ROW(i) (AKF ? (tid / MF_KD) + (NT / MF_KD) * (i) : (tid & (MF_BM - 1)))
+#define A_KL(i) (AKF ? (tid % MF_KD) : (tid / MF_BM) + (NT / MF_BM) * (i))
+#define B_ROW(i) (BKF ? (tid / MF_KD) + (NT / MF_KD) * (i) : (tid & (MF_BN - 1)))
+#define B_KL(i) (BKF ? (tid % MF_KD) : (tid / MF_BN) + (NT / MF_BN) * (i))
+#define MF_ISSUE(KT)                                                                                       \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
+            const int m = tm * MF_BM + A_ROW(i), ka = (KT) + A_KL(i);                                      \
+            bool oka = (m < M) & (ka < k1);                                                                \
+            int ia = off_of<AK>(d.A, m, ka, oka);                                                          \
+            ia = oka ? ia : 0;                                                                             \
+            const float x = baseA[(unsigned)ia];                                                           \
+            if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                       \
+                const float y = baseA2[(unsigned)ia];                                                      \
+                const int col = (AK == OPK_ACTGRAD) ? (a_tr ? m : ka) : 0;                                 \
+                ya[i] = act_bwd(a_act, y, col);                                                            \
+            } else ya[i] = 1.f;                                                                            \
+            va[i] = oka ? x : 0.f;                                                                         \
+            const int n = tn * MF_BN + B_ROW(i), kb = (KT) + B_KL(i);                                      \
+            bool okb = (n < N) & (kb < k1);                                                                \
+            const bool one = okb & (n == b_ones);                                                          \
+            int ib = off_of<BKIND>(d.B, kb, n, okb);                                                       \
+            ib = (okb & !one) ? ib : 0;                                                                    \
+            const float w = baseB[(unsigned)ib];                                                           \
+            vb[i] = one ? 1.f : (okb ? w : 0.f);                                                           \
+        }                                                                                                  \
+    }
+    if (k0 < k1) MF_ISSUE(k0)
+    for (int kt = k0; kt < k1; kt += MF_KD) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            As[A_KL(i)][A_ROW(i)] = (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) ? va[i] * ya[i] : va[i];
+            Bs[B_KL(i)][B_ROW(i)] = vb[i];
+        }
+        __syncthreads();
+        if (kt + MF_KD < k1) MF_ISSUE(kt + MF_KD)          // next tile's loads fly under this tile's MFMAs
+        if (live) {
+#pragma unroll
+            for (int kk = 0; kk < MF_KD / 2; ++kk) {
+                const int k = kk * 2 + (lane >> 5);
+                const float a = As[k][wm * 32 + (lane & 31)];
+                const float bb = Bs[k][wn * 32 + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef MF_ISSUE
+#undef A_ROW
+#undef A_KL
+#undef B_ROW
+#undef B_KL
+    if (!live) return;
+    float* cbase = b.p[d.out.space] + d.out.off;
+    const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
+    const int n = tn * MF_BN + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = tm * MF_BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < N) store_out<OK>(d, cbase, bias, m, n, split, acc[r]);
+    }
+}
+
+__global__ __launch_bounds__(MF_THREADS) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, int count, int blocks_per_clip, Bases b) {
+    __shared__ float smem[2 * MF_KD * (MF_BM + 4)];
+    float (*As)[MF_BM + 4] = reinterpret_cast<float (*)[MF_BM + 4]>(smem);
+    float (*Bs)[MF_BN + 4] = reinterpret_cast<float (*)[MF_BN + 4]>(smem + MF_KD * (MF_BM + 4));
+    const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
+    int y = 0;
+    while (y + 1 < count && lb >= descs[y + 1].blk_begin) ++y;
+    const GemmDesc d = descs[clip * count + y];
+    const int local = lb - d.blk_begin;
+    const int ntile = ((d.M + MF_BM - 1) / MF_BM) * ((d.N + MF_BN - 1) / MF_BN);
+    const int tile = local % ntile, split = local / ntile;
+    switch (d.variant) {
+    case GV_LIN_FWD: gemm_mfma_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_FWD_PERM: gemm_mfma_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DW: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DW_PERM: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+    case GV_LIN_DA: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, tile, split, As, Bs); break;
+    case GV_CONV_FWD: gemm_mfma_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs); break;
+    case GV_CONV_DW: gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs); break;
+    case GV_HH_DW: gemm_mfma_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
+    default: break;
+    }
+}
+
+int gemm_tile_edge(int mfma) { return mfma ? MF_BM : GEMM_BM; }
+
 // One kernel for every GEMM of the model: blockIdx.y picks the descriptor, the descriptor's
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
@@ -258,9 +387,10 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, Bases b, hipStream_t s) {
+int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s) {
     if (members <= 0 || blocks_per_clip <= 0 || clips <= 0) return 0;
-    hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
+    if (mfma) hipLaunchKernelGGL(gemm_mfma_kernel, dim3(blocks_per_clip * clips), dim3(MF_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
+    else hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
     return (int)hipGetLastError();
 }
 

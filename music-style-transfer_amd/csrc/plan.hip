@@ -224,6 +224,7 @@ struct mst_plan {
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     int err = 0;
     int nlanes = 1;
+    int mfma = 0;                 // GEMM flavour of this plan: 1 = f32 MFMA 64x64 tiles (batched, FLOP-bound plans), 0 = latency kernel
     struct LaneCtx { std::vector<hipStream_t> side; std::vector<hipEvent_t> ev; hipEvent_t start = nullptr; };
     mutable std::map<std::pair<hipStream_t, int>, LaneCtx> lane_ctx;   // per (caller stream, pass): side streams + step events
                                                                         // (an event is recorded once per capture)
@@ -916,7 +917,8 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 for (int q = 0; q < nm; ++q) {
                     const GemmDesc& g0 = s_gemms[m.first + q];
                     for (int k = 0; k < copies; ++k) s_gemms[m.first + k * nm + q].blk_begin = total;
-                    total += tiles(g0.M, g0.N) * g0.ksplit;
+                    const int edge = gemm_tile_edge(mfma);
+                    total += ((g0.M + edge - 1) / edge) * ((g0.N + edge - 1) / edge) * g0.ksplit;
                 }
                 m.a = total; m.b = nm;        // blocks per clip, members per clip
             }
@@ -964,6 +966,10 @@ void mst_plan::schedule() {
     // experimental, default off: on ROCm 7.2 the cross-stream graph edges cost more than the overlap returns
     // (815 -> 870 it/s with 2 lanes, 741 with 4; nested inside another capture fork hipStreamEndCapture crashes)
     nlanes = env ? atoi(env) : 1;
+    // one clip per launch is latency-bound (the 32x32 split-K kernel); from a few clips per launch on the GEMMs are
+    // FLOP-bound and go to the matrix cores.  MST_GEMM=mfma|valu overrides (experiments, tests).
+    const char* ge = getenv("MST_GEMM");
+    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 4);
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
     std::vector<Step> fwd, bwd;
@@ -1066,7 +1072,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.b, s.a, s.count / s.b, b, st);
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);

@@ -256,6 +256,27 @@ static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     return c;
 }
 
+// f32 MFMA 32x32x2: lane l supplies A[row=l&31][k=l>>5] and B[k=l>>5][col=l&31];
+// D register r of lane l is C[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]; k-ordered fmaf chain.
+typedef float hipsim_f32x16 __attribute__((ext_vector_type(16)));
+static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int) {
+    using namespace hipsim;
+    State& s = st();
+    int lin = lin_tid(), w = lin / WAVE, lane = lin % WAVE;
+    s.slot_f[w][lane][0] = a;
+    s.slot_f[w][lane][1] = b;
+    wave_barrier();
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(s.slot_f[w][row + 32 * k][0], s.slot_f[w][col + 32 * k][1], acc);
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+
 // ---- host-side runtime bits used by plan.hip
 using std::max;
 using std::min;

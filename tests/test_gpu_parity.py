@@ -65,3 +65,10 @@ def test_batched_clips_full_widths(native):
 def test_batched_64_bench_clips_equal_sequential(native):
     # BASELINE.json configs[2] at full size: 64 x (C=4, R=16, T=4) clips in one plan == 64 one-clip iterations, bit for bit
     pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, 64, check_oracle=False)
+
+
+def test_single_clip_on_the_mfma_gemm(native, monkeypatch):
+    monkeypatch.setenv('MST_GEMM', 'mfma')
+    pc.golden_small(native, torch.device('cuda:0'), 'small_unpitched')
+    e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, check_bitwise=True)
+    print('bench clip on MFMA: all-gradient rel-L2', e, 'worst tensor', worst)

@@ -40,3 +40,14 @@ def test_empty_clip_has_finite_losses():
 @pytest.mark.parametrize('C,R,T,unp,K', [(2, 2, 2, True, 3), (1, 3, 1, False, 2)])
 def test_batched_clips_equal_sequential_iterations(C, R, T, unp, K):
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, C, R, T, unp, K)
+
+
+def test_batched_clips_on_the_mfma_gemm():
+    # K >= 4 clips per launch switches the plan's GEMMs to the f32-MFMA kernel (emulated k-ordered fmaf chain here)
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4)
+
+
+def test_single_clip_on_the_mfma_gemm(monkeypatch):
+    monkeypatch.setenv('MST_GEMM', 'mfma')
+    pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True)
+    pc.golden_small(sim_native(), 'cpu', 'small_unpitched')
