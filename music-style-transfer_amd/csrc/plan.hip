@@ -288,8 +288,14 @@ struct mst_plan {
     }
     int64_t tmp(int64_t n) { int64_t o = tmp_top; tmp_top += align(n); return o; }
     static int tiles(int M, int N) { return ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN); }
-    // weight-gradient GEMMs reduce over rows: one k-split per 256 rows (2 k-tiles), capped at 64 slabs
-    static int splits_for(int K) { int s = (K + 255) / 256; return s < 1 ? 1 : (s > 64 ? 64 : s); }
+    // weight-gradient GEMMs reduce over rows.  One clip per launch (latency-bound): one k-split per 256 rows (2 k-tiles),
+    // capped at 64 slabs, for workgroup count.  Batched plans get their parallelism from the clips, so a split covers
+    // up to 2048 rows (64 MFMA k-tiles, at 64 clips) and the slab traffic of the deferred reduction shrinks accordingly.
+    int splits_for(int rows) const {
+        const int per = 32 * K() < 256 ? 256 : (32 * K() > 2048 ? 2048 : 32 * K());
+        int s = (rows + per - 1) / per;
+        return s < 1 ? 1 : (s > 64 ? 64 : s);
+    }
 
     static SegIn seg(const T& t, int s0, int s1, int s2, int s3, bool grad = true) {
         return SegIn{SP_WS, t.off, t.ld, t.cols, {s0, s1, s2, s3}, grad};
@@ -623,7 +629,10 @@ void mst_plan::build() {
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
         n.out_off = mel_c.off; n.g_out_off = mel_c.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
         const int nw = z.ME_CW * NPF + z.ME_CW + z.MEL * (z.MEL + z.ME_CW) + z.MEL;
-        n.nblk = P_ < 256 ? P_ : 256; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        // workgroups (= weight-gradient slabs) per clip: a batched plan gets its parallelism from the clips, and every
+        // slab is one more row the deferred reduction has to sum serially per weight element
+        const int me_blk = K() == 1 ? 256 : (2048 / K() < 4 ? 4 : (2048 / K() > 256 ? 256 : 2048 / K()));
+        n.nblk = P_ < me_blk ? P_ : me_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = E;
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
@@ -676,7 +685,8 @@ void mst_plan::build() {
         n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
         const int qf = Q_ * NF;
-        n.nblk = qf < 512 ? qf : 512; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        const int psa_blk = K() == 1 ? 512 : (4096 / K() < 8 ? 8 : (4096 / K() > 512 ? 512 : 4096 / K()));
+        n.nblk = qf < psa_blk ? qf : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});

@@ -145,10 +145,21 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     per-clip activations and losses are bit-identical, and so is the summed gradient (same order)."""
     dims1 = make_dims(widths, C, R, T, unp)
     dimsK = make_dims(widths, C, R, T, unp, clips=K)
+    # a plan picks its GEMM flavour from the clip count (K >= 4: f32 MFMA, else the latency kernel); the bitwise
+    # comparison needs both plans on the same one
+    old_flavour = os.environ.get('MST_GEMM')
+    os.environ['MST_GEMM'] = 'mfma' if K >= 4 else 'valu'
+    try:
+        planK = nat.Plan(native, dimsK, device)
+        plan1 = nat.Plan(native, dims1, device)
+    finally:
+        if old_flavour is None:
+            del os.environ['MST_GEMM']
+        else:
+            os.environ['MST_GEMM'] = old_flavour
     flat, named, table = random_params(native, dims1, seed)
     clips = [synth_clip(10 + k, C, R, T, unp, density=density) for k in range(K)]
     params = flat.to(device)
-    planK = nat.Plan(native, dimsK, device)
     assert planK.clips == K
     for k, clip in enumerate(clips):
         planK.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
@@ -159,7 +170,6 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     lossesK = torch.zeros(K, nat.N_LOSSES, device=device)
     planK.train_iteration(params, gK, xp, xu, lossesK)
     # (b) one-clip plan, K sequential iterations
-    plan1 = nat.Plan(native, dims1, device)
     g1 = torch.zeros_like(params)
     losses1 = torch.zeros(nat.N_LOSSES, device=device)
     names = ['style', 'melody', 'rhythm', 'pitched_pred', 'instruments_pred', 'mode_pred', 'bpm_pred'] + (['unpitched_pred'] if unp else [])

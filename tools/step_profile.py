@@ -17,16 +17,20 @@ from style import _native as nat
 shape = dict(CLIP)
 if len(sys.argv) >= 4:
     shape = dict(C=int(sys.argv[1]), R=int(sys.argv[2]), T=int(sys.argv[3]))
+K = int(sys.argv[4]) if len(sys.argv) >= 5 else 1          # clips per launch (batched plan)
 dev = torch.device('cuda:0')
 native = nat.get()
 native.lib.mst_plan_step_info.restype = C.c_int32
-dims = nat.Dims(**shape, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+dims = nat.Dims(**shape, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1, clips=K)
 flat, table = init_params(native, dims)
-clip = synth_clip(0, shape['C'], shape['R'], shape['T'], True)
+clips = [synth_clip(k, shape['C'], shape['R'], shape['T'], True) for k in range(K)]
 plan = native.plan(dims, dev)
-plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'], used=clip['used_instruments'], bpm_target=120.)
+for k, clip in enumerate(clips):
+    plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'], used=clip['used_instruments'],
+                    bpm_target=120., clip=k)
 params = flat.to(dev); g = torch.zeros_like(params)
-xp, xu = clip['pitched'].to(dev), clip['unpitched'].to(dev)
+xp = torch.cat([c['pitched'] for c in clips]).contiguous().to(dev)
+xu = torch.cat([c['unpitched'] for c in clips]).contiguous().to(dev)
 plan.train_iteration(params, g, xp, xu)
 torch.cuda.synchronize()
 tot = 0
@@ -38,5 +42,5 @@ for bwd in (False, True):
     print('==== backward' if bwd else '==== forward')
     for i, ((kind, ms, fl, by), inf) in enumerate(zip(steps, info)):
         tot += ms
-        print(f'{i:3d} {KIND_NAMES[kind]:22s} {ms*1e3:8.1f} us  {fl/1e6:9.2f} MFLOP {by/1e6:8.2f} MB  info={inf.tolist()}')
+        print(f'{i:3d} {KIND_NAMES[kind]:22s} {ms*1e3:8.1f} us  {fl/1e6:9.2f} MFLOP {by/1e6:8.2f} MB  {fl/ms/1e9:7.2f} TF {by/ms/1e6:7.1f} GB/s  info={inf.tolist()}')
 print('sum of steps: %.3f ms' % tot)
