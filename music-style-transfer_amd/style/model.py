@@ -441,6 +441,15 @@ class _Loss(torch.autograd.Function):
         return g_pp, None, g_up, None, g_il, None, g_ml, None, g_bp, None, None
 
 
+class LossDict(dict):
+    """The reference's nested loss dict; `.packed` is the 15-leaf device tensor behind it (key order
+    `_native.LOSS_KEYS`, NaN for absent unpitched leaves) so a training loop can log without a sync per leaf."""
+
+    def __init__(self, packed, **items):
+        super().__init__(**items)
+        self.packed = packed
+
+
 def get_total_loss(instruments_pred, instruments_target, mode_pred, mode_target, bpm_pred, bpm_target,
                    pitched_pred, pitched_target, unpitched_pred=None, unpitched_target=None, normalize=False):
     """Same nested dict as the reference (style/model.py:944-996).  Positional contract preserved: the
@@ -464,7 +473,7 @@ def get_total_loss(instruments_pred, instruments_target, mode_pred, mode_target,
                          velocity_loss=L[k['channels_loss_unpitched_velocity_loss']],
                          duration_loss=L[k['channels_loss_unpitched_duration_loss']])
     one = lambda name: L[k[name]:k[name] + 1]      # shape (1,), like the reference's bpm-derived leaves
-    return dict(
+    return LossDict(L.detach(),
         total=one('total'),
         channels_loss=dict(total=L[k['channels_loss_total']], pitched=pitched, unpitched=unpitched),
         song_info_loss=dict(total=one('song_info_loss_total'), instruments_loss=L[k['song_info_loss_instruments_loss']],
