@@ -93,6 +93,7 @@ def test_train_loop_matches_oracle_trajectory(tmp_path):
     songs = [st.get_model_input(p) for p in SONGS]
     model = build_model(seed=108)
     named = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    start = torch.cat([p.detach().reshape(-1) for p in named.values()])
     csv_path, snap = str(tmp_path / 'training.csv'), str(tmp_path / 'snapshots')
     train(model, iter(songs), n_iterations=4, iter_size=2, training_info_path=csv_path, save_path=snap, save_interval=2,
           flush_every=3, progress=False)
@@ -113,9 +114,13 @@ def test_train_loop_matches_oracle_trajectory(tmp_path):
             assert rows[it]['channels_loss_unpitched_total'] == ''
         if (it + 1) % 2 == 0:
             opt.step()
-    for n, p in model.named_parameters():
-        ref = named[n].detach()
-        assert float((p.detach().cpu() - ref).abs().max()) < 2e-3, n
+    # Adam's first steps move every weight by ~lr * sign(g): where |g| is at rounding level the sign is noise, so the
+    # comparison is on the update vector as a whole (2 steps of lr = .01 => |delta| <= .02 per element)
+    got = torch.cat([p.detach().cpu().reshape(-1) for _, p in model.named_parameters()]) - start
+    want = torch.cat([p.detach().reshape(-1) for p in named.values()]) - start
+    assert float(want.abs().max()) <= .0201 and float(got.abs().max()) <= .0201
+    assert float((got - want).norm() / want.norm()) < 2e-2
+    assert float(((got - want).abs() > 1e-3).float().mean()) < 2e-3
     # whole-module snapshot loads back (train-model.py:156-160)
     loaded = torch.load(os.path.join(snap, '2.pkl'), weights_only=False)
     assert type(loaded).__name__ == 'StyleTransferModel'
