@@ -312,13 +312,13 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
     }
 }
 
-__global__ __launch_bounds__(MF_THREADS) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, int count, int blocks_per_clip, Bases b) {
+__global__ __launch_bounds__(MF_THREADS) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
     __shared__ float smem[2 * MF_KD * (MF_BM + 4)];
     float (*As)[MF_BM + 4] = reinterpret_cast<float (*)[MF_BM + 4]>(smem);
     float (*Bs)[MF_BN + 4] = reinterpret_cast<float (*)[MF_BN + 4]>(smem + MF_KD * (MF_BM + 4));
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
     int y = 0;
-    while (y + 1 < count && lb >= descs[y + 1].blk_begin) ++y;
+    while (y + 1 < count && lb >= starts[y + 1]) ++y;          // starts[]: one cache line, not one descriptor per probe
     const GemmDesc d = descs[clip * count + y];
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + MF_BM - 1) / MF_BM) * ((d.N + MF_BN - 1) / MF_BN);
@@ -342,7 +342,7 @@ int gemm_tile_edge(int mfma) { return mfma ? MF_BM : GEMM_BM; }
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
 // all small Linears of one dependency level — into a single launch.
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, int count, int blocks_per_clip, Bases b) {
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
     // A tile | B tile; the final reduce overlays the whole block with one 32x32 partial tile per wave
     constexpr int TILE_F = GEMM_BK * (GEMM_BM + 4), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
     __shared__ float smem[(2 * TILE_F > RED_F) ? 2 * TILE_F : RED_F];
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __re
     // flat 1-D grid: clip-major; inside a clip's block range member y owns [blk_begin, blk_begin + tiles * ksplit)
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
     int y = 0;
-    while (y + 1 < count && lb >= descs[y + 1].blk_begin) ++y;
+    while (y + 1 < count && lb >= starts[y + 1]) ++y;          // starts[]: one cache line, not one descriptor per probe
     const GemmDesc d = descs[clip * count + y];      // by value (scalar loads once): a reference would be re-read after every barrier
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
@@ -387,10 +387,10 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s) {
+int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s) {
     if (members <= 0 || blocks_per_clip <= 0 || clips <= 0) return 0;
-    if (mfma) hipLaunchKernelGGL(gemm_mfma_kernel, dim3(blocks_per_clip * clips), dim3(MF_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
-    else hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, members, blocks_per_clip, b);
+    if (mfma) hipLaunchKernelGGL(gemm_mfma_kernel, dim3(blocks_per_clip * clips), dim3(MF_THREADS), 0, s, dev_descs, dev_starts, members, blocks_per_clip, b);
+    else hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, dev_starts, members, blocks_per_clip, b);
     return (int)hipGetLastError();
 }
 

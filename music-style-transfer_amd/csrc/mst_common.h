@@ -171,7 +171,8 @@ int gemm_variant(const GemmDesc& g);
 // descs = clips x members (clip-major); every clip's copy of a member has the same blk_begin inside the clip's block range
 // mfma = 1: the 64x64-tile f32-MFMA kernel (throughput), 0: the 32x32 split-K kernel (latency); blk_begin must have been
 // computed with the matching tile edge (gemm_tile_edge)
-int launch_gemm(const GemmDesc* dev_descs, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
+// dev_starts: the members' blk_begin values as a dense int array (index = position of the clip-0 descriptor)
+int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
 int gemm_tile_edge(int mfma);
 int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s);
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);

@@ -214,6 +214,7 @@ struct mst_plan {
     const std::vector<Step>& list(int mask, int backward) const { return mask == MST_STAGE_ALL ? sched_all[backward ? 1 : 0] : sched[backward ? 1 : 0]; }
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
     std::vector<CombineDesc> s_combines; std::vector<NotesDesc> s_notes;
+    std::vector<int> s_gemm_starts; int* d_gemm_starts = nullptr;      // blk_begin of every scheduled GEMM descriptor, densely
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
@@ -1004,6 +1005,9 @@ int mst_plan::upload() {
     int e = 0;
     e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
     e |= up(s_combines, &d_combines); e |= up(s_notes, &d_notes);
+    s_gemm_starts.resize(s_gemms.size());
+    for (size_t i = 0; i < s_gemms.size(); ++i) s_gemm_starts[i] = s_gemms[i].blk_begin;
+    e |= up(s_gemm_starts, &d_gemm_starts);
     for (int s = 0; s < 3; ++s) {
         for (auto& ent : slabs[s]) { ent.reps = K(); ent.rep_stride = tmp_top; }
         e |= up(slabs[s], &d_slabs[s]);
@@ -1032,6 +1036,7 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
+    hipFree(p->d_gemm_starts);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
     for (auto& kv : p->lane_ctx) {
@@ -1082,7 +1087,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
+    case K_GEMM: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
