@@ -178,20 +178,20 @@ def main():
             return
         if os.environ.get('MST_BENCH_SEQ'):      # experiment: accumulation iterations back to back on one stream
             iteration(0); iteration(1)
-            return
-        for j in (0, 1):
-            side[j].wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side[j]):
-                iteration(j)
-        for j in (0, 1):
-            torch.cuda.current_stream(dev).wait_stream(side[j])
+        else:
+            for j in (0, 1):
+                side[j].wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side[j]):
+                    iteration(j)
+            for j in (0, 1):
+                torch.cuda.current_stream(dev).wait_stream(side[j])
+        if dist is not None:                     # one buffer for the collective; part of the replayed graph
+            grads[0].add_(grads[1])
+            grads[1].zero_()
 
     def optimizer_step():
         st = nat.current_stream(dev)
         if dist is not None:
-            if not batched:
-                grads[0].add_(grads[1])
-                grads[1].zero_()
             dist.all_reduce(grads[0], op=dist.ReduceOp.SUM)          # sum, not mean: train-model.py:126,151-153
         if dist is not None or batched:
             nat.check(native.lib.mst_adam_step(P(params), P(grads[0]), P(m), P(v), n, P(state), .01, .9, .999, 1e-8, 200, .9,

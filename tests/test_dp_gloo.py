@@ -56,3 +56,52 @@ def test_two_rank_sum_allreduce_equals_reference_accumulation(tmp_path):
     r = torch.load(out)
     assert r['same'], 'ranks diverged after the all-reduced step'
     assert r['worst'] < 3e-4, r['worst']
+
+
+def _worker_batched(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'music-style-transfer_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle.synth import synth_clip
+    from parity_cases import SMALL, random_params
+    from simutil import make_dims, sim_native
+    from style import _native as nat
+    C, R, T, B = 2, 2, 2, 2                       # B clips per rank in one batched plan (BASELINE.json configs[3] in miniature)
+    native = sim_native()
+    flat, _, _ = random_params(native, make_dims(SMALL, C, R, T, True), seed=3)
+
+    def run(clip_ids, reduce):
+        plan = nat.Plan(native, make_dims(SMALL, C, R, T, True, clips=len(clip_ids)), 'cpu')
+        clips = [synth_clip(i, C, R, T, True, density=.05) for i in clip_ids]
+        for k, c in enumerate(clips):
+            plan.set_inputs(mode=c['mode'], bpm=c['bpm'], instr=c['instruments_features'], used=c['used_instruments'],
+                            bpm_target=float(c['bpm_int']), clip=k)
+        params, g = flat.clone(), torch.zeros_like(flat)
+        plan.train_iteration(params, g, torch.cat([c['pitched'] for c in clips]).contiguous(),
+                             torch.cat([c['unpitched'] for c in clips]).contiguous())
+        if reduce:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        m, v, state = torch.zeros_like(params), torch.zeros_like(params), torch.zeros(4)
+        nat.check(native.lib.mst_adam_step(nat.ptr(params), nat.ptr(g), nat.ptr(m), nat.ptr(v), params.numel(), nat.ptr(state),
+                                           .01, .9, .999, 1e-8, 200, .9, 1, None), 'adam')
+        return params, g
+
+    p_dp, _ = run([rank * B + k for k in range(B)], True)            # this rank's B clips, then all-reduce(SUM)
+    if rank == 0:
+        p_one, _ = run(list(range(world * B)), False)                 # all clips in one process = iter_size = world * B
+        torch.save(dict(delta=float((p_dp - p_one).abs().max()), moved=float((p_one - flat).abs().max())), out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_of_batched_clips_equal_one_rank_with_all_clips(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from simutil import sim_native
+    sim_native()
+    out = str(tmp_path / 'dpb.pt')
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_batched, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['moved'] > 5e-3                      # Adam moved the weights by ~lr
+    assert r['delta'] < 2e-4, r                   # ... identically, up to the summation order of the gradient
