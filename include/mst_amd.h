@@ -146,7 +146,8 @@ int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_
 
 /* ---- instrumentation (bench.py only; synchronises on HIP events, never used for training):
  * average duration of every launch step of a pass, with its algorithmic FLOPs and bytes.
- * kind: 0 gemm, 1 gather, 2 segment-reduce, 3/4 lstm fwd/bwd, 5/6 combine fwd/bwd, 7/8 melody notes, 9/10 applier notes. */
+ * kind: 0 gemm, 1 gather, 2 segment-reduce, 3/4 lstm fwd/bwd, 5/6 combine fwd/bwd, 7/8 melody notes, 9/10 applier notes,
+ * 11 lstm weight transpose, 12/13 row-wise tiny Linear fwd/bwd. */
 int32_t mst_plan_step_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
 int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 5 ints per step */);
 int32_t mst_plan_time_steps(const mst_plan* p, int32_t stage_mask, int32_t backward, const float* params,

@@ -141,6 +141,16 @@ struct NotesDesc {
     int64_t slab_off; int32_t slab_stride; int32_t nblk;
 };
 
+// ---- row-wise tiny Linear: y[r, :] = act(W x[r, :] + b) with K_in <= 8 and N_out <= 20 over very many rows
+// (PitchedStyleApplier.melody_linear 8->20 over positions x 56 notes, UnpitchedStyleApplier.linear 8->2 over
+// positions x 47 notes; style/model.py:606-610,660-662,694-701,722-723).  As GEMMs these are all tile padding.
+struct RowLinDesc {
+    int32_t rows, kin, nout, act, xgrad;
+    int64_t x_off, y_off;        // [SP_WS] rows x kin / rows x nout, contiguous; gradients at the same offsets in SP_GRAD
+    int64_t w_off, b_off;        // [SP_PAR] weight (nout x kin) immediately followed by bias (nout)
+    int64_t slab_off; int32_t slab_stride, nblk;   // [SP_TMP] one row of nout*kin + nout partial weight gradients per workgroup
+};
+
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
 struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; };
@@ -194,6 +204,9 @@ int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* 
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
                      const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
                      hipStream_t s);
+bool rowlin_supported(int kin, int nout);
+int launch_rowlin_fwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);
+int launch_rowlin_bwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s);
 bool notes_widths_supported(int W, int CW, int ML);
 

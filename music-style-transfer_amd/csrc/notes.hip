@@ -344,3 +344,143 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
     PSA_DISPATCH(psa_notes_bwd_kernel, dim3(h.nblk, count), dim3(256));
     return (int)hipGetLastError();
 }
+
+// ============================================================================ row-wise tiny Linear
+// One lane per row: the K_in inputs and N_out outputs of a row live in registers, the weights are
+// LDS-broadcast, rows are read / written with the widest aligned vector the widths allow.  Backward
+// does input gradient and weight gradient in one pass: each lane keeps all N_out*(K_in+1) weight-
+// gradient partials in registers across its grid-stride loop, then the workgroup reduces them in a
+// fixed order (wave butterfly, then waves 0..3) into its slab row.  No float atomics.
+__device__ __forceinline__ float rl_act(int act, float z, int col) {
+    if (act == ACT_LEAKY) return lrelu(z);
+    if (act == ACT_SIGOUT) { const float s = 1.f / (1.f + expf(-z)); return col == 0 ? 6.f * s : s; }
+    return z;
+}
+__device__ __forceinline__ float rl_dact(int act, float y, int col) {
+    if (act == ACT_LEAKY) return dlrelu(y);
+    if (act == ACT_SIGOUT) return col == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y);
+    return 1.f;
+}
+template <int N>
+__device__ __forceinline__ void rl_load(const float* p, float* v) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) { const float4 t = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { const float2 t = reinterpret_cast<const float2*>(p)[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+}
+template <int N>
+__device__ __forceinline__ void rl_store(float* p, const float* v) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) reinterpret_cast<float2*>(p)[i] = make_float2(v[2 * i], v[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = v[i];
+    }
+}
+
+template <int KIN, int NOUT>
+__global__ __launch_bounds__(256) void rowlin_fwd_kernel(const RowLinDesc* __restrict__ dp, Bases b) {
+    const RowLinDesc d = dp[blockIdx.y];
+    __shared__ float w_s[NOUT * KIN], b_s[NOUT];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NOUT * KIN; i += 256) w_s[i] = b.p[SP_PAR][d.w_off + i];
+    if (tid < NOUT) b_s[tid] = b.p[SP_PAR][d.b_off + tid];
+    __syncthreads();
+    const float* x0 = b.p[SP_WS] + d.x_off;
+    float* y0 = b.p[SP_WS] + d.y_off;
+    for (int row = blockIdx.x * 256 + tid; row < d.rows; row += gridDim.x * 256) {
+        float x[KIN], y[NOUT];
+        rl_load<KIN>(x0 + (int64_t)row * KIN, x);
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            float z = b_s[n];
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) z = fmaf(w_s[n * KIN + k], x[k], z);
+            y[n] = rl_act(d.act, z, n);
+        }
+        rl_store<NOUT>(y0 + (int64_t)row * NOUT, y);
+    }
+}
+
+template <int KIN, int NOUT>
+__global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __restrict__ dp, Bases b) {
+    const RowLinDesc d = dp[blockIdx.y];
+    constexpr int NACC = NOUT * KIN + NOUT;
+    __shared__ float w_s[NOUT * KIN];
+    __shared__ float red[4][NACC];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NOUT * KIN; i += 256) w_s[i] = b.p[SP_PAR][d.w_off + i];
+    __syncthreads();
+    const float* x0 = b.p[SP_WS] + d.x_off;
+    const float* y0 = b.p[SP_WS] + d.y_off;
+    const float* gy0 = b.p[SP_GRAD] + d.y_off;
+    float* gx0 = b.p[SP_GRAD] + d.x_off;
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+    for (int row = blockIdx.x * 256 + tid; row < d.rows; row += gridDim.x * 256) {
+        float x[KIN], y[NOUT], g[NOUT];
+        rl_load<KIN>(x0 + (int64_t)row * KIN, x);
+        rl_load<NOUT>(y0 + (int64_t)row * NOUT, y);
+        rl_load<NOUT>(gy0 + (int64_t)row * NOUT, g);
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            g[n] *= rl_dact(d.act, y[n], n);
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) acc[n * KIN + k] = fmaf(g[n], x[k], acc[n * KIN + k]);
+            acc[NOUT * KIN + n] += g[n];
+        }
+        if (d.xgrad) {
+            float dx[KIN];
+            rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int n = 0; n < NOUT; ++n) a = fmaf(g[n], w_s[n * KIN + k], a);
+                dx[k] += a;
+            }
+            rl_store<KIN>(gx0 + (int64_t)row * KIN, dx);
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        float v = acc[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][a] = v;
+    }
+    __syncthreads();
+    for (int a = tid; a < NACC; a += 256)
+        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + a] = (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]);
+}
+
+bool rowlin_supported(int kin, int nout) { return (kin == 8 && nout == 20) || (kin == 4 && nout == 14) || (kin == 8 && nout == 2); }
+
+#define ROWLIN_DISPATCH(KERN, GRID)                                                                         \
+    if (h.kin == 8 && h.nout == 20) hipLaunchKernelGGL((KERN<8, 20>), GRID, dim3(256), 0, s, dev, b);         \
+    else if (h.kin == 4 && h.nout == 14) hipLaunchKernelGGL((KERN<4, 14>), GRID, dim3(256), 0, s, dev, b);    \
+    else if (h.kin == 8 && h.nout == 2) hipLaunchKernelGGL((KERN<8, 2>), GRID, dim3(256), 0, s, dev, b);      \
+    else return MST_ERR_UNSUPPORTED;
+
+int launch_rowlin_fwd(const RowLinDesc* dev, const RowLinDesc& h, int count, Bases b, hipStream_t s) {
+    int nb = (h.rows + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    ROWLIN_DISPATCH(rowlin_fwd_kernel, dim3(nb, count));
+    return (int)hipGetLastError();
+}
+int launch_rowlin_bwd(const RowLinDesc* dev, const RowLinDesc& h, int count, Bases b, hipStream_t s) {
+    ROWLIN_DISPATCH(rowlin_bwd_kernel, dim3(h.nblk, count));
+    return (int)hipGetLastError();
+}

@@ -191,7 +191,7 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 // ------------------------------------------------------------------------------------------ plan
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
-enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T };
+enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B };
 struct Step {
     int kind, first, count, a, b, stage;
     int lane = 0;                 // dataflow lane (0 = the caller's stream)
@@ -206,14 +206,15 @@ static int stage_idx(int stage) { return stage == MST_STAGE_EXTRACT ? 0 : stage 
 struct mst_plan {
     mst_dims d; Sizes z; ParamTable pt;
     std::vector<GemmDesc> gemms; std::vector<GatherDesc> gathers; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
-    std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<SlabEntry> slabs[3];
+    std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<RowLinDesc> rowlins; std::vector<SlabEntry> slabs[3];
     std::vector<Op> ops;
     // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
     std::vector<Step> sched[2];        // per-stage merging (stages may run separately)
     std::vector<Step> sched_all[2];    // stage-agnostic merging, used when all stages run together
     const std::vector<Step>& list(int mask, int backward) const { return mask == MST_STAGE_ALL ? sched_all[backward ? 1 : 0] : sched[backward ? 1 : 0]; }
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
-    std::vector<CombineDesc> s_combines; std::vector<NotesDesc> s_notes;
+    std::vector<CombineDesc> s_combines; std::vector<NotesDesc> s_notes; std::vector<RowLinDesc> s_rowlins;
+    RowLinDesc* d_rowlins = nullptr;
     std::vector<int> s_gemm_starts; int* d_gemm_starts = nullptr;      // blk_begin of every scheduled GEMM descriptor, densely
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
@@ -272,6 +273,10 @@ struct mst_plan {
         const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
         c.x_off += a; c.out_off += a; c.gx_off += a; c.gout_off += a; c.stats_off += t; c.part_off += t;
         return c;
+    }
+    RowLinDesc reloc(RowLinDesc r, int k) const {
+        r.x_off += shift(SP_WS, k); r.y_off += shift(SP_WS, k); r.slab_off += shift(SP_TMP, k);
+        return r;
     }
     NotesDesc reloc(NotesDesc n, int k) const {
         const int64_t a = shift(SP_WS, k);
@@ -496,6 +501,25 @@ struct mst_plan {
         lstm_group(stage, {LstmSpec{x, B, S, H, reverse, pre, out, coloff}});
     }
 
+    // nn.Linear with K_in <= 8 over a very tall, contiguous input: one lane per row instead of a GEMM of tile padding
+    T rowlin(int stage, const T& x, bool xgrad, const std::string& pre, int N, int act, const char* name = nullptr) {
+        if (!rowlin_supported(x.cols, N) || x.ld != x.cols) return linear(stage, x, xgrad, pre, N, act, name);
+        T out = newT(x.rows, N, name);
+        RowLinDesc r{}; r.rows = x.rows; r.kin = x.cols; r.nout = N; r.act = act; r.xgrad = xgrad ? 1 : 0;
+        r.x_off = x.off; r.y_off = out.off; r.w_off = pt.off(pre + ".weight"); r.b_off = pt.off(pre + ".bias");
+        if (r.b_off != r.w_off + (int64_t)N * x.cols) err = MST_ERR_UNSUPPORTED;
+        const int want = (x.rows + 255) / 256;
+        const int cap = K() == 1 ? 128 : (1024 / K() < 4 ? 4 : (1024 / K() > 128 ? 128 : 1024 / K()));
+        r.nblk = want < cap ? want : cap;
+        r.slab_stride = N * x.cols + N; r.slab_off = tmp((int64_t)r.slab_stride * r.nblk);
+        Op op; op.stage = stage;
+        op.fwd.push_back(Step{K_ROW_F, (int)rowlins.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_ROW_B, (int)rowlins.size(), 1, 0, 0});
+        rowlins.push_back(r); ops.push_back(op);
+        slabs[stage_idx(stage)].push_back(SlabEntry{r.w_off, r.slab_off, r.slab_stride, r.slab_stride, r.nblk});
+        return out;
+    }
+
     void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out) {
         CombineDesc c{}; c.Cn = Cn; c.rows = rows; c.cols = cols; c.ld = ld; c.x_off = x_off; c.cs = cs; c.out_off = out.off;
         c.stats_off = tmp(64); c.part_off = tmp(COMBINE_MAXBLK * (COMBINE_MAXC + 1));
@@ -677,7 +701,7 @@ void mst_plan::build() {
     T acat = gather(AP, rsCQF, {seg0(psa_sl), seg(psa_rl, 0, 1, 0, 0), seg(psa_il, 1, 0, 0, 0)});
     T lo = linear(AP, acat, true, m + ".octave_linear", NPF * 6 * NOCT, ACT_LEAKY);
     T ld_ = linear(AP, acat, true, m + ".scale_degree_linear", NPF * 6 * NDEG, ACT_LEAKY);
-    T ml = linear(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
+    T ml = rowlin(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
@@ -703,7 +727,7 @@ void mst_plan::build() {
         T ucat = gather(AP, rsQ_F, {seg(sl_view, 0, 1, 0, 0), seg(usa_rl, NF, 1, 0, 0)});
         T v = linear(AP, ucat, true, m + ".notes_linear", NUN * NUF * 4, ACT_LEAKY);
         T v_rows{v.off, Q_ * NF * NUN, NUF * 4, NUF * 4};                  // x.view(..., n_unpitched_notes, -1)
-        linear(AP, v_rows, true, m + ".linear", NUF, ACT_SIGOUT, "unpitched_pred");
+        rowlin(AP, v_rows, true, m + ".linear", NUF, ACT_SIGOUT, "unpitched_pred");
     }
     stage_end[2] = act_top;
     if (!notes_widths_supported(z.MEL, z.ME_CW, z.PSA_ML)) err = MST_ERR_UNSUPPORTED;
@@ -823,6 +847,18 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             }
             break;
         }
+        case K_ROW_F: case K_ROW_B: {
+            const RowLinDesc& r = rowlins[s.first + i];
+            const int64_t nx = (int64_t)r.rows * r.kin, ny = (int64_t)r.rows * r.nout;
+            acc_add(v, SP_WS, r.x_off, nx, false);
+            acc_add(v, SP_WS, r.y_off, ny, s.kind == K_ROW_F);
+            if (s.kind == K_ROW_B) {
+                acc_add(v, SP_GRAD, r.y_off, ny, false);
+                if (r.xgrad) acc_add(v, SP_GRAD, r.x_off, nx, true);
+                acc_add(v, SP_TMP, r.slab_off, (int64_t)r.slab_stride * r.nblk, true);
+            }
+            break;
+        }
         case K_ME_F: case K_ME_B: case K_PSA_F: case K_PSA_B: {
             const NotesDesc& n = notes[s.first + i];
             const bool me = s.kind == K_ME_F || s.kind == K_ME_B, bwd = s.kind == K_ME_B || s.kind == K_PSA_B;
@@ -887,6 +923,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             else if (is_lstm) m.first = (int)s_lstms.size();
             else if (is_comb) m.first = (int)s_combines.size();
             else if (is_notes) m.first = (int)s_notes.size();
+            else if (s0.kind == K_ROW_F || s0.kind == K_ROW_B) m.first = (int)s_rowlins.size();
             std::vector<int> members;                       // indices into the per-kind descriptor vectors (one clip)
             for (int j = i; j < n; ++j) {
                 if (done[j] || level[j] != lv) continue;
@@ -919,6 +956,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                     else if (is_lstm) s_lstms.push_back(reloc(lstms[idx], k));
                     else if (is_comb) s_combines.push_back(reloc(combines[idx], k));
                     else if (is_notes) s_notes.push_back(reloc(notes[idx], k));
+                    else if (s0.kind == K_ROW_F || s0.kind == K_ROW_B) s_rowlins.push_back(reloc(rowlins[idx], k));
                 }
             }
             m.count = (int)members.size() * copies;
@@ -1004,7 +1042,7 @@ static int up(const std::vector<D>& v, D** dev) {
 int mst_plan::upload() {
     int e = 0;
     e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
-    e |= up(s_combines, &d_combines); e |= up(s_notes, &d_notes);
+    e |= up(s_combines, &d_combines); e |= up(s_notes, &d_notes); e |= up(s_rowlins, &d_rowlins);
     s_gemm_starts.resize(s_gemms.size());
     for (size_t i = 0; i < s_gemms.size(); ++i) s_gemm_starts[i] = s_gemms[i].blk_begin;
     e |= up(s_gemm_starts, &d_gemm_starts);
@@ -1036,7 +1074,7 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
-    hipFree(p->d_gemm_starts);
+    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
     for (auto& kv : p->lane_ctx) {
@@ -1095,6 +1133,8 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, b, st);
     case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, b, st);
+    case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
+    case K_ROW_B: return launch_rowlin_bwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
@@ -1278,6 +1318,14 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
             const double n = (double)c.rows * c.cols;
             f += n * c.Cn * (s.kind == K_COMB_F ? 4.0 : 8.0);
             b += 4.0 * n * (s.kind == K_COMB_F ? 2.0 * c.Cn + 1 : 4.0 * c.Cn + 2);
+        }
+        break;
+    case K_ROW_F: case K_ROW_B:
+        for (int i = 0; i < s.count; ++i) {
+            const RowLinDesc& r = p->s_rowlins[s.first + i];
+            const double mm = 2.0 * r.rows * r.kin * r.nout;
+            f += s.kind == K_ROW_F ? mm : 2.0 * mm;
+            b += 4.0 * r.rows * (s.kind == K_ROW_F ? r.kin + r.nout : 2.0 * r.kin + 2.0 * r.nout + (r.xgrad ? r.kin : 0));
         }
         break;
     case K_ME_F: case K_ME_B: {
