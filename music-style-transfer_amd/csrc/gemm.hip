@@ -435,42 +435,52 @@ int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipSt
 // Segments reduced over <= 64 rows finish here (dst +=); wider ones leave per-chunk partials that
 // stage 2 sums in chunk order (deterministic; no float atomics).
 #define SEGRED_CHUNK 64
-__global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
-    const SegRedDesc d = descs[blockIdx.y];
-    if ((int)blockIdx.x >= d.nidx * d.nchunk) return;
-    const int idx = blockIdx.x / d.nchunk, chunk = blockIdx.x - idx * d.nchunk;
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    int kc[4], t = idx;
+// Stage 1, one lane per (destination row, chunk, column): the lane walks its chunk's reduced rows with an
+// odometer over the reduced dims (no divisions in the loop), four loads in flight, and adds them in row
+// order.  No LDS, no barriers, and a workgroup always has 256 outputs' worth of work (a workgroup per
+// destination row left most lanes idle: the broadcast segments are 5-48 columns wide).
+__global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, int members, int blocks_per_clip, Bases b) {
+    // flat grid, clip-major: inside a clip's block range member y owns [blk_begin, blk_begin + ceil(nidx*nchunk*width / 256))
+    const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
+    int y = 0;
+    while (y + 1 < members && lb >= descs[y + 1].blk_begin) ++y;
+    const SegRedDesc d = descs[clip * members + y];
+    const int e = (lb - d.blk_begin) * 256 + threadIdx.x;
+    if (e >= d.nidx * d.nchunk * d.width) return;
+    const int w = e % d.width;
+    int t = e / d.width;
+    const int chunk = t % d.nchunk, idx = t / d.nchunk;
+    int kc[4];
+    t = idx;
 #pragma unroll
     for (int q = 3; q >= 0; --q) { kc[q] = t % d.kd[q]; t /= d.kd[q]; }
     int rd[4], nred = 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { rd[q] = d.kd[q] == 1 ? d.d[q] : 1; nred *= rd[q]; }
     const int r_begin = chunk * SEGRED_CHUNK, r_end = min(nred, r_begin + SEGRED_CHUNK);
-    const float* src = b.p[SP_GRAD] + d.src_off;
-    float* dst = d.nchunk == 1 ? b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld
-                               : b.p[SP_TMP] + d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width;
-    for (int w0 = 0; w0 < d.width; w0 += 64) {
-        const int w = w0 + lane;
-        float acc = 0.f;
-        if (w < d.width) {
-            for (int rr = r_begin + grp; rr < r_end; rr += 4) {
-                int c[4], u = rr;
+    int cr[4];
+    t = r_begin;
 #pragma unroll
-                for (int q = 3; q >= 0; --q) { c[q] = kc[q] + u % rd[q]; u /= rd[q]; }
-                const int64_t row = (((int64_t)c[0] * d.d[1] + c[1]) * d.d[2] + c[2]) * d.d[3] + c[3];
-                acc += src[row * d.src_ld + d.start + w];
-            }
-        }
-        part[grp][lane] = acc;
-        __syncthreads();
-        if (grp == 0 && w < d.width) {
-            const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-            if (d.nchunk == 1) dst[w] += v; else dst[w] = v;
-        }
-        __syncthreads();
+    for (int q = 3; q >= 0; --q) { cr[q] = t % rd[q]; t /= rd[q]; }
+    const float* src = b.p[SP_GRAD] + d.src_off + d.start + w;
+    const int64_t s3 = d.src_ld, s2 = s3 * d.d[3], s1 = s2 * d.d[2], s0 = s1 * d.d[1];
+    auto offset = [&]() { return (kc[0] + cr[0]) * s0 + (kc[1] + cr[1]) * s1 + (kc[2] + cr[2]) * s2 + (kc[3] + cr[3]) * s3; };
+    auto advance = [&]() {
+        if (++cr[3] == rd[3]) { cr[3] = 0; if (++cr[2] == rd[2]) { cr[2] = 0; if (++cr[1] == rd[1]) { cr[1] = 0; ++cr[0]; } } }
+    };
+    float acc = 0.f;
+    int rr = r_begin;
+    for (; rr + 4 <= r_end; rr += 4) {
+        const int64_t o0 = offset(); advance();
+        const int64_t o1 = offset(); advance();
+        const int64_t o2 = offset(); advance();
+        const int64_t o3 = offset(); advance();
+        const float v0 = src[o0], v1 = src[o1], v2 = src[o2], v3 = src[o3];
+        acc += v0; acc += v1; acc += v2; acc += v3;
     }
+    for (; rr < r_end; ++rr) { acc += src[offset()]; advance(); }
+    if (d.nchunk == 1) b.p[SP_GRAD][d.dst_off + (int64_t)idx * d.dst_ld + w] += acc;
+    else b.p[SP_TMP][d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width + w] = acc;
 }
 
 __global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
@@ -486,9 +496,10 @@ __global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restri
     }
 }
 
-int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s) {
-    if (count <= 0) return 0;
-    hipLaunchKernelGGL(segred_kernel, dim3(max_blocks, count), dim3(256), 0, s, dev_descs, b);
+int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip, int clips, int stage2_blocks, Bases b, hipStream_t s) {
+    const int count = members * clips;
+    if (count <= 0 || blocks_per_clip <= 0) return 0;
+    hipLaunchKernelGGL(segred_kernel, dim3(blocks_per_clip * clips), dim3(256), 0, s, dev_descs, members, blocks_per_clip, b);
     if (stage2_blocks > 0) hipLaunchKernelGGL(segred2_kernel, dim3(stage2_blocks, count), dim3(256), 0, s, dev_descs, b);
     return (int)hipGetLastError();
 }

@@ -100,6 +100,7 @@ struct SegRedDesc {
     int32_t kd[4];       // kept-dim sizes (1 where reduced)
     int32_t nchunk;      // chunks of 64 reduced rows; > 1 => partials at part_off, summed by stage 2
     int64_t part_off;    // [SP_TMP] nidx * nchunk * width
+    int32_t blk_begin;   // first workgroup of this member inside its clip's block range of the (merged) launch
 };
 
 // ---- LSTM recurrence
@@ -184,7 +185,7 @@ int gemm_variant(const GemmDesc& g);
 // dev_starts: the members' blk_begin values as a dense int array (index = position of the clip-0 descriptor)
 int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
 int gemm_tile_edge(int mfma);
-int launch_segred(const SegRedDesc* dev_descs, int count, int max_blocks, int stage2_blocks, Bases b, hipStream_t s);
+int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip, int clips, int stage2_blocks, Bases b, hipStream_t s);
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);

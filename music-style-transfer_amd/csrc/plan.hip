@@ -971,6 +971,16 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 }
                 m.a = total; m.b = nm;        // blocks per clip, members per clip
             }
+            if (m.kind == K_SEGRED) {    // same flat layout; m.b keeps the stage-2 block count, members = count / clips
+                const int nm = (int)members.size();
+                int total = 0;
+                for (int q = 0; q < nm; ++q) {
+                    const SegRedDesc& r0 = s_segreds[m.first + q];
+                    for (int k = 0; k < copies; ++k) s_segreds[m.first + k * nm + q].blk_begin = total;
+                    total += (r0.nidx * r0.nchunk * r0.width + 255) / 256;
+                }
+                m.a = total;
+            }
             out.push_back(m);
             macc.push_back(std::move(mac));
         }
@@ -1127,7 +1137,7 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     switch (s.kind) {
     case K_GEMM: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
-    case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count, s.a, s.b, b, st);
+    case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count / p->K(), s.a, p->K(), s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
     case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
