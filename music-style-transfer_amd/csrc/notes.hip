@@ -348,9 +348,10 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
 // ============================================================================ row-wise tiny Linear
 // One lane per row: the K_in inputs and N_out outputs of a row live in registers, the weights are
 // LDS-broadcast, rows are read / written with the widest aligned vector the widths allow.  Backward
-// does input gradient and weight gradient in one pass: each lane keeps all N_out*(K_in+1) weight-
-// gradient partials in registers across its grid-stride loop, then the workgroup reduces them in a
-// fixed order (wave butterfly, then waves 0..3) into its slab row.  No float atomics.
+// does input gradient and weight gradient in one pass: every lane stages its row's dZ and x in LDS,
+// then "role" lanes (one per weight / bias element) sum the 256 staged rows in row order and keep
+// their element in a register across the grid-stride loop — one slab row per workgroup, no shuffles,
+// no float atomics.
 __device__ __forceinline__ float rl_act(int act, float z, int col) {
     if (act == ACT_LEAKY) return lrelu(z);
     if (act == ACT_SIGOUT) { const float s = 1.f / (1.f + expf(-z)); return col == 0 ? 6.f * s : s; }
@@ -415,55 +416,64 @@ __global__ __launch_bounds__(256) void rowlin_fwd_kernel(const RowLinDesc* __res
 template <int KIN, int NOUT>
 __global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __restrict__ dp, Bases b) {
     const RowLinDesc d = dp[blockIdx.y];
-    constexpr int NACC = NOUT * KIN + NOUT;
+    constexpr int NACC = NOUT * KIN + NOUT;            // weight (NOUT x KIN) then bias (NOUT), the parameters' own order
+    constexpr int RW = (NOUT + KIN) | 1;               // staged row: dZ[NOUT] | x[KIN], odd stride => conflict-free row writes
+    static_assert(NACC <= 256, "role count exceeds the workgroup");
     __shared__ float w_s[NOUT * KIN];
-    __shared__ float red[4][NACC];
+    __shared__ float st[256][RW];
     const int tid = threadIdx.x;
     for (int i = tid; i < NOUT * KIN; i += 256) w_s[i] = b.p[SP_PAR][d.w_off + i];
-    __syncthreads();
     const float* x0 = b.p[SP_WS] + d.x_off;
     const float* y0 = b.p[SP_WS] + d.y_off;
     const float* gy0 = b.p[SP_GRAD] + d.y_off;
     float* gx0 = b.p[SP_GRAD] + d.x_off;
-    float acc[NACC];
+    // role lanes: lane t < NOUT*KIN owns dW[n][k], the next NOUT lanes own db[n]; each sums the 256 staged rows of a
+    // pass in row order and keeps its element in a register across the grid-stride loop (one slab row per workgroup)
+    const int rn = tid < NOUT * KIN ? tid / KIN : tid - NOUT * KIN;
+    const int rk = tid < NOUT * KIN ? NOUT + tid % KIN : -1;
+    float wacc = 0.f;
+    for (int base = blockIdx.x * 256; base < d.rows; base += gridDim.x * 256) {
+        const int row = base + tid;
+        __syncthreads();                                // previous pass's role reads are done (and w_s is loaded)
+        if (row < d.rows) {
+            float x[KIN], y[NOUT], g[NOUT];
+            rl_load<KIN>(x0 + (int64_t)row * KIN, x);
+            rl_load<NOUT>(y0 + (int64_t)row * NOUT, y);
+            rl_load<NOUT>(gy0 + (int64_t)row * NOUT, g);
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
-    for (int row = blockIdx.x * 256 + tid; row < d.rows; row += gridDim.x * 256) {
-        float x[KIN], y[NOUT], g[NOUT];
-        rl_load<KIN>(x0 + (int64_t)row * KIN, x);
-        rl_load<NOUT>(y0 + (int64_t)row * NOUT, y);
-        rl_load<NOUT>(gy0 + (int64_t)row * NOUT, g);
+            for (int n = 0; n < NOUT; ++n) { g[n] *= rl_dact(d.act, y[n], n); st[tid][n] = g[n]; }
 #pragma unroll
-        for (int n = 0; n < NOUT; ++n) {
-            g[n] *= rl_dact(d.act, y[n], n);
+            for (int k = 0; k < KIN; ++k) st[tid][NOUT + k] = x[k];
+            if (d.xgrad) {
+                float dx[KIN];
+                rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
 #pragma unroll
-            for (int k = 0; k < KIN; ++k) acc[n * KIN + k] = fmaf(g[n], x[k], acc[n * KIN + k]);
-            acc[NOUT * KIN + n] += g[n];
-        }
-        if (d.xgrad) {
-            float dx[KIN];
-            rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
+                for (int k = 0; k < KIN; ++k) {
+                    float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < KIN; ++k) {
-                float a = 0.f;
-#pragma unroll
-                for (int n = 0; n < NOUT; ++n) a = fmaf(g[n], w_s[n * KIN + k], a);
-                dx[k] += a;
+                    for (int n = 0; n < NOUT; ++n) a = fmaf(g[n], w_s[n * KIN + k], a);
+                    dx[k] += a;
+                }
+                rl_store<KIN>(gx0 + (int64_t)row * KIN, dx);
             }
-            rl_store<KIN>(gx0 + (int64_t)row * KIN, dx);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NOUT + KIN; ++j) st[tid][j] = 0.f;
+        }
+        __syncthreads();
+        if (tid < NACC) {
+            float a = 0.f;
+            if (rk >= 0) {
+#pragma unroll 8
+                for (int r = 0; r < 256; ++r) a = fmaf(st[r][rn], st[r][rk], a);
+            } else {
+#pragma unroll 8
+                for (int r = 0; r < 256; ++r) a += st[r][rn];
+            }
+            wacc += a;
         }
     }
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        float v = acc[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wv][a] = v;
-    }
-    __syncthreads();
-    for (int a = tid; a < NACC; a += 256)
-        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + a] = (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]);
+    if (tid < NACC) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
 }
 
 bool rowlin_supported(int kin, int nout) { return (kin == 8 && nout == 20) || (kin == 4 && nout == 14) || (kin == 8 && nout == 2); }

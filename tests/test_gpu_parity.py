@@ -72,3 +72,9 @@ def test_single_clip_on_the_mfma_gemm(native, monkeypatch):
     pc.golden_small(native, torch.device('cuda:0'), 'small_unpitched')
     e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, check_bitwise=True)
     print('bench clip on MFMA: all-gradient rel-L2', e, 'worst tensor', worst)
+
+
+def test_oracle_training_cap_shape(native):
+    # the reference's own cap: songs are cut to 800 // C bars for training (train-model.py:101) => C=4, R=200, T=4
+    e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 200, 4, True, clip_id=11)
+    print('training cap: all-gradient rel-L2', e, 'worst tensor', worst)
