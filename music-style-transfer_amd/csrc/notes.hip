@@ -91,35 +91,44 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
         float odacc = 0.f;                  // this lane's octave / degree gradient element
         for (int f = 0; f < NF; ++f) {
             __syncthreads();
-            if (tid < NPN) {
-                const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+            // note phase on all four waves: wave w handles every note (lane = note) for the cat elements
+            // i in [w*IQ, w*IQ + IQ); the note's 8 output gradients are re-read by each wave (L1 hits)
+            if ((tid & 63) < NPN) {
+                constexpr int IQ = (KL + 3) / 4;
+                const int wv = tid >> 6, n = tid & 63, o = n / NDEG, dg = n - o * NDEG;
                 const int64_t pos = (int64_t)p * NF * NPN + f * NPN + n;
-                float cat[KL];
+                float x5[NPF];
 #pragma unroll
-                for (int i = 0; i < NPF; ++i) x_s[n][i] = x[pos * NPF + i];
-#pragma unroll
-                for (int j = 0; j < W; ++j) cat[j] = lrelu(oct_s[o * W + j] + deg_s[dg * W + j]);
-#pragma unroll
-                for (int k = 0; k < CW; ++k) {
-                    float z = bc_s[k];
-#pragma unroll
-                    for (int i = 0; i < NPF; ++i) z = fmaf(wc_s[k * NPF + i], x_s[n][i], z);
-                    cat[W + k] = lrelu(z);
-                }
+                for (int i = 0; i < NPF; ++i) x5[i] = x[pos * NPF + i];
                 float gm[W];
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    gm[j] = b.p[SP_GRAD][d.g_out_off + pos * W + j] * dlrelu(ws[d.out_off + pos * W + j]);
-                    gm_s[n][j] = gm[j];
+                for (int j = 0; j < W; ++j) gm[j] = b.p[SP_GRAD][d.g_out_off + pos * W + j] * dlrelu(ws[d.out_off + pos * W + j]);
+                if (wv == 0) {
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) x_s[n][i] = x5[i];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) gm_s[n][j] = gm[j];
                 }
 #pragma unroll
-                for (int i = 0; i < KL; ++i) {
-                    float g = 0.f;
+                for (int ii = 0; ii < IQ; ++ii) {
+                    const int i = wv * IQ + ii;
+                    if (i < KL) {
+                        float c;
+                        if (i < W) {
+                            c = lrelu(oct_s[o * W + i] + deg_s[dg * W + i]);
+                        } else {
+                            float z = bc_s[i - W];
 #pragma unroll
-                    for (int j = 0; j < W; ++j) g = fmaf(gm[j], wl_s[j * KL + i], g);
-                    g *= dlrelu(cat[i]);
-                    cat_s[n][i] = cat[i];
-                    if (i < W) god_s[n][i] = g; else gc_s[n][i - W] = g;
+                            for (int q = 0; q < NPF; ++q) z = fmaf(wc_s[(i - W) * NPF + q], x5[q], z);
+                            c = lrelu(z);
+                        }
+                        float g = 0.f;
+#pragma unroll
+                        for (int j = 0; j < W; ++j) g = fmaf(gm[j], wl_s[j * KL + i], g);
+                        g *= dlrelu(c);
+                        cat_s[n][i] = c;
+                        if (i < W) god_s[n][i] = g; else gc_s[n][i - W] = g;
+                    }
                 }
             }
             __syncthreads();
@@ -127,16 +136,16 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
                 float a = 0.f;
                 if (tid >= R_BL) {
                     const int j = tid - R_BL;
-                    for (int n = 0; n < NPN; ++n) a += gm_s[n][j];
+                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a += gm_s[n][j];
                 } else if (tid >= R_WL) {
                     const int j = (tid - R_WL) / KL, i = (tid - R_WL) % KL;
-                    for (int n = 0; n < NPN; ++n) a = fmaf(gm_s[n][j], cat_s[n][i], a);
+                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a = fmaf(gm_s[n][j], cat_s[n][i], a);
                 } else if (tid >= R_BC) {
                     const int k = tid - R_BC;
-                    for (int n = 0; n < NPN; ++n) a += gc_s[n][k];
+                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a += gc_s[n][k];
                 } else {
                     const int k = tid / NPF, i = tid % NPF;
-                    for (int n = 0; n < NPN; ++n) a = fmaf(gc_s[n][k], x_s[n][i], a);
+                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a = fmaf(gc_s[n][k], x_s[n][i], a);
                 }
                 wacc += a;
             }
@@ -154,8 +163,9 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
                 odacc += a;
             }
         }
-        if (tid < NOCT * W) b.p[SP_GRAD][d.g_oct_off + (int64_t)p * NOCT * W + tid] += odacc;
-        else if (tid < (NOCT + NDEG) * W) b.p[SP_GRAD][d.g_deg_off + (int64_t)p * NDEG * W + (tid - NOCT * W)] += odacc;
+        // sole writer of these rows: store, not read-modify-write
+        if (tid < NOCT * W) b.p[SP_GRAD][d.g_oct_off + (int64_t)p * NOCT * W + tid] = odacc;
+        else if (tid < (NOCT + NDEG) * W) b.p[SP_GRAD][d.g_deg_off + (int64_t)p * NDEG * W + (tid - NOCT * W)] = odacc;
     }
     if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
 }
@@ -232,20 +242,34 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
     for (int i = tid; i < NPF * KL; i += 256) w_s[i] = par[d.wl_off + i];
     float* ws = b.p[SP_WS];
     const int QF = d.Q * NF;
-    const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+    // note phase on all four waves: lane = note, wave w handles hidden features j in [8w, 8w + 8) and the melody-linear
+    // gradients k in [w*KQ, w*KQ + KQ); the note's 5 output gradients are re-read by each wave (L1 hits)
+    constexpr int JQ = (PSA_HW + 3) / 4, KQ = (ML + 3) / 4;
+    const int wv = tid >> 6, n = tid & 63, o = n / NDEG, dg = n - o * NDEG;
     float wacc = 0.f;
+    // the octave | degree rows of the NEXT (qf, c) are fetched into two registers per lane while the current one is
+    // processed, so their global-load latency is not paid at every barrier
+    constexpr int NOD = NLO + NLD;                      // 450 <= 2 * 256
+    float od0 = 0.f, od1 = 0.f;
+    auto fetch_od = [&](int64_t row) {
+        od0 = tid < NLO ? ws[d.oct_off + row * NLO + tid] : ws[d.deg_off + row * NLD + (tid - NLO)];
+        if (tid + 256 < NOD) od1 = ws[d.deg_off + row * NLD + (tid + 256 - NLO)];
+    };
+    if ((int)blockIdx.x < QF) fetch_od((int64_t)blockIdx.x);
     for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
         __syncthreads();
         for (int i = tid; i < NPN * ML; i += 256) ml_s[i / ML][i % ML] = ws[d.ml_off + (int64_t)qf * NPN * ML + i];
-        float gml[ML];
+        float gml[KQ];
 #pragma unroll
-        for (int k = 0; k < ML; ++k) gml[k] = 0.f;
+        for (int k = 0; k < KQ; ++k) gml[k] = 0.f;
         for (int c = 0; c < d.C; ++c) {
             const int64_t row = (int64_t)c * QF + qf;
             __syncthreads();
-            for (int i = tid; i < NLO; i += 256) lo_s[i] = ws[d.oct_off + row * NLO + i];
-            for (int i = tid; i < NLD; i += 256) ld_s[i] = ws[d.deg_off + row * NLD + i];
+            if (tid < NLO) lo_s[tid] = od0; else ld_s[tid - NLO] = od0;
+            if (tid + 256 < NOD) ld_s[tid + 256 - NLO] = od1;
             __syncthreads();
+            if (c + 1 < d.C) fetch_od((int64_t)(c + 1) * QF + qf);
+            else if (qf + (int)gridDim.x < QF) fetch_od((int64_t)(qf + gridDim.x));
             if (n < NPN) {
                 const int64_t pos = row * NPN + n;
                 float dz[NPF];
@@ -254,23 +278,29 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                     const float y = ws[d.out_off + pos * NPF + i];
                     const float dy = b.p[SP_GRAD][d.g_out_off + pos * NPF + i];
                     dz[i] = dy * (i == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y));
-                    dz_s[n][i] = dz[i];
+                    if (wv == 0) dz_s[n][i] = dz[i];
                 }
 #pragma unroll
-                for (int j = 0; j < PSA_HW; ++j) {
-                    const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
-                    float g = 0.f;
+                for (int jj = 0; jj < JQ; ++jj) {
+                    const int j = wv * JQ + jj;
+                    if (j < PSA_HW) {
+                        const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
+                        float g = 0.f;
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + j], g);
-                    h_s[n][j] = h;
-                    dh_s[n][j] = g * dlrelu(h);
+                        for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + j], g);
+                        h_s[n][j] = h;
+                        dh_s[n][j] = g * dlrelu(h);
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < ML; ++k) {
-                    float g = 0.f;
+                for (int kk = 0; kk < KQ; ++kk) {
+                    const int k = wv * KQ + kk;
+                    if (k < ML) {
+                        float g = 0.f;
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + PSA_HW + k], g);
-                    gml[k] += g;
+                        for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + PSA_HW + k], g);
+                        gml[kk] += g;
+                    }
                 }
             }
             __syncthreads();
@@ -278,11 +308,12 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                 float a = 0.f;
                 if (tid >= NPF * KL) {
                     const int i = tid - NPF * KL;
-                    for (int m = 0; m < NPN; ++m) a += dz_s[m][i];
+                    // (unrolled: 8+ independent LDS reads in flight instead of one read latency per note)
+                    _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a += dz_s[m][i];
                 } else {
                     const int i = tid / KL, jj = tid % KL;
-                    if (jj < PSA_HW) { for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], h_s[m][jj], a); }
-                    else { for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], ml_s[m][jj - PSA_HW], a); }
+                    if (jj < PSA_HW) { _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], h_s[m][jj], a); }
+                    else { _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], ml_s[m][jj - PSA_HW], a); }
                 }
                 wacc += a;
             }
@@ -292,19 +323,22 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                     const int oo = r / PSA_HW, j = r % PSA_HW;
 #pragma unroll
                     for (int q = 0; q < NDEG; ++q) a += dh_s[oo * NDEG + q][j];
-                    b.p[SP_GRAD][d.g_oct_off + row * NLO + r] += a;
+                    b.p[SP_GRAD][d.g_oct_off + row * NLO + r] = a;      // sole writer of this row: store, not read-modify-write
                 } else {
                     const int q = (r - NLO) / PSA_HW, j = (r - NLO) % PSA_HW;
 #pragma unroll
                     for (int oo = 0; oo < NOCT; ++oo) a += dh_s[oo * NDEG + q][j];
-                    b.p[SP_GRAD][d.g_deg_off + row * NLD + (r - NLO)] += a;
+                    b.p[SP_GRAD][d.g_deg_off + row * NLD + (r - NLO)] = a;
                 }
             }
         }
         if (n < NPN) {
             float* g = b.p[SP_GRAD] + d.g_ml_off + ((int64_t)qf * NPN + n) * ML;
 #pragma unroll
-            for (int k = 0; k < ML; ++k) g[k] += gml[k];
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int k = wv * KQ + kk;
+                if (k < ML) g[k] = gml[kk];                            // sole writer (all channels summed above)
+            }
         }
     }
     if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
