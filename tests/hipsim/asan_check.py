@@ -16,7 +16,7 @@ lib = C.CDLL(os.path.join(HERE, 'libmst_sim_asan.so'))
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('C', 'R', 'T', 'beat', 'bar', 'nrf', 'style', 'melody', 'rhythm',
-                                         'instr', 'n_instruments', 'has_unpitched')]
+                                         'instr', 'n_instruments', 'has_unpitched', 'clips')]
 
 
 lib.mst_plan_create.restype = C.c_void_p
@@ -25,8 +25,12 @@ lib.mst_param_floats.restype = C.c_int64
 P = C.c_void_p
 
 
-def run(C_, R, T, widths, unp):
-    d = Dims(C_, R, T, *widths, 51, 41, int(unp))
+def run(C_, R, T, widths, unp, clips=1, gemm=None):
+    if gemm:
+        os.environ['MST_GEMM'] = gemm
+    else:
+        os.environ.pop('MST_GEMM', None)
+    d = Dims(C_, R, T, *widths, 51, 41, int(unp), clips)
     st = C.c_int32()
     plan = C.c_void_p(lib.mst_plan_create(C.byref(d), C.byref(st)))
     assert plan.value, st.value
@@ -35,9 +39,9 @@ def run(C_, R, T, widths, unp):
     params = (rng.standard_normal(n) * 0.1).astype(np.float32)
     g = np.zeros(n, np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
     ws = np.zeros(lib.mst_plan_workspace_floats(plan), np.float32)
-    pitched = (rng.random((C_ * R * T * 10 * 56, 5)) * (rng.random((C_ * R * T * 10 * 56, 1)) < 0.05)).astype(np.float32)
-    unpitched = (rng.random((R * T * 10 * 47, 2)) * (rng.random((R * T * 10 * 47, 1)) < 0.05)).astype(np.float32)
-    losses = np.zeros(15, np.float32); state = np.zeros(4, np.float32)
+    pitched = (rng.random((clips * C_ * R * T * 10 * 56, 5)) * (rng.random((clips * C_ * R * T * 10 * 56, 1)) < 0.05)).astype(np.float32)
+    unpitched = (rng.random((clips * R * T * 10 * 47, 2)) * (rng.random((clips * R * T * 10 * 47, 1)) < 0.05)).astype(np.float32)
+    losses = np.zeros(15 * clips, np.float32); state = np.zeros(4, np.float32)
     a = lambda x: x.ctypes.data_as(P)
     for it in range(2):
         e = lib.mst_train_iteration(plan, a(params), a(g), a(ws), a(pitched), a(unpitched) if unp else None, a(losses), None)
@@ -45,11 +49,15 @@ def run(C_, R, T, widths, unp):
     lib.mst_adam_step.argtypes = [P, P, P, P, C.c_int64, P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_int32, P]
     assert lib.mst_adam_step(a(params), a(g), a(m), a(v), n, a(state), .01, .9, .999, 1e-8, 200, .9, 1, None) == 0
     lib.mst_plan_destroy(plan)
-    print('ok', (C_, R, T), widths, unp, 'total loss', float(losses[0]), 'finite grads', bool(np.isfinite(params).all()))
+    print('ok', (C_, R, T), widths, unp, 'clips', clips, gemm or 'default gemm', 'total loss', float(losses[0]), 'finite grads', bool(np.isfinite(params).all()))
 
 
 run(2, 3, 2, (8, 6, 3, 12, 4, 6), True)
 run(3, 2, 3, (8, 6, 3, 12, 4, 6), False)
 run(1, 1, 1, (64, 128, 8, 256, 8, 32), True)
 run(2, 2, 4, (64, 128, 8, 256, 8, 32), True)
+run(2, 3, 2, (8, 6, 3, 12, 4, 6), True, clips=3)                    # batched plan, latency GEMM
+run(2, 2, 1, (8, 6, 3, 12, 4, 6), True, clips=5)                    # batched plan on the MFMA GEMM
+run(2, 2, 2, (64, 128, 8, 256, 8, 32), True, clips=4)
+run(3, 2, 3, (64, 128, 8, 256, 8, 32), False, gemm='mfma')          # one clip on the MFMA GEMM
 print('asan pass clean')
