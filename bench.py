@@ -81,10 +81,12 @@ def cpu_baseline(flat, table, clip, seconds):
                        f'mkldnn LSTM), {dt:.1f} s')
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, clips=1):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/), or None.
-    bench.py cannot run the profiler on itself; the counters are collected by the command recorded in the file."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    bench.py cannot run the profiler on itself; the counters are collected by the command recorded in the file
+    (one file per workload: one clip per launch, 64 clips per launch)."""
+    name = 'r01_pmc_hbm_traffic.json' if clips == 1 else f'r01_pmc_hbm_traffic_{clips}_clips.json'
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         d = json.load(open(path))
         return d[kernel]['hbm_bytes_per_launch'] if kernel in d else None
@@ -266,9 +268,15 @@ def main():
                                        gflop=round(fl / 1e9, 4), mbytes=round(by / 1e6, 2)))
             kind, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
             achieved = fl / (ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel=KIND_NAMES[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+            names = dict(KIND_NAMES)
+            if os.environ.get('MST_GEMM', 'mfma' if K >= 4 else 'valu') == 'mfma':
+                names[0] = 'gemm_mfma_kernel'            # plans with >= 4 clips per launch run their GEMMs on the matrix cores
+            for r in table_rows:
+                if r['kernel'] == 'gemm_kernel':
+                    r['kernel'] = names[0]
+            roof = dict(bound='mfma', kernel=names[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
                         flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(KIND_NAMES[kind]),
+                        frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(names[kind], K),
                         clips_per_launch=K,
                         whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
                                              achieved_tflops=algorithmic_flops_per_iter(**CLIP) / (dt / args.steps) / 1e12))
