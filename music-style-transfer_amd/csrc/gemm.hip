@@ -509,29 +509,32 @@ int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip,
 // order (bitwise reproducible, unlike float atomics).  p.grad accumulates across iterations
 // exactly like loss.backward() does in train-model.py:126.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __restrict__ ents, const SlabBlock* __restrict__ blocks, Bases b) {
-    const SlabBlock blk = blocks[blockIdx.x];       // 1024 consecutive elements of one entry
+    const SlabBlock blk = blocks[blockIdx.x];       // 64 consecutive elements of one entry
     const SlabEntry e = ents[blk.entry];
+    // rows of an entry = (clip, k-split / producer workgroup) pairs, clip-major.  Lanes walk 64 consecutive elements
+    // (256-byte rows); the four waves take a contiguous quarter of the rows each, then the quarters are added in order.
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int rows = e.reps * e.splits;
+    const int r0 = (int)((int64_t)rows * g / 4), r1 = (int)((int64_t)rows * (g + 1) / 4);
+    const int i = blk.start + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;              // 4 independent chains keep 4+ loads in flight
+    if (i < e.count) {
+        const float* src = b.p[SP_TMP] + e.src + i;
+        int rep = r0 / e.splits, sp = r0 - rep * e.splits;
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            int64_t o[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = blk.start + q * 256 + threadIdx.x;
-        if (i < e.count) {
-            float total = 0.f;
-            for (int r = 0; r < e.reps; ++r) {                  // clips of a batched plan, in order
-                const float* src = b.p[SP_TMP] + e.src + (int64_t)r * e.rep_stride + i;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains keep 4+ loads in flight
-                int sp = 0;
-                for (; sp + 4 <= e.splits; sp += 4) {
-                    a0 += src[(int64_t)sp * e.stride];
-                    a1 += src[(int64_t)(sp + 1) * e.stride];
-                    a2 += src[(int64_t)(sp + 2) * e.stride];
-                    a3 += src[(int64_t)(sp + 3) * e.stride];
-                }
-                for (; sp < e.splits; ++sp) a0 += src[(int64_t)sp * e.stride];
-                total += (a0 + a1) + (a2 + a3);
-            }
-            b.p[SP_GPAR][e.dst + i] += total;
+            for (int q = 0; q < 4; ++q) { o[q] = (int64_t)rep * e.rep_stride + (int64_t)sp * e.stride; if (++sp == e.splits) { sp = 0; ++rep; } }
+            const float v0 = src[o[0]], v1 = src[o[1]], v2 = src[o[2]], v3 = src[o[3]];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
+        for (; r < r1; ++r) { a0 += src[(int64_t)rep * e.rep_stride + (int64_t)sp * e.stride]; if (++sp == e.splits) { sp = 0; ++rep; } }
     }
+    part[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && i < e.count) b.p[SP_GPAR][e.dst + i] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s) {

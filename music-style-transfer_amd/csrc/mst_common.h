@@ -155,7 +155,7 @@ struct RowLinDesc {
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
 struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; };
-struct SlabBlock { int32_t entry, start; };   // one workgroup's 1024-element slice of an entry
+struct SlabBlock { int32_t entry, start; };   // one workgroup's 64-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)
 struct Sizes {

@@ -1060,7 +1060,7 @@ int mst_plan::upload() {
         for (auto& ent : slabs[s]) { ent.reps = K(); ent.rep_stride = tmp_top; }
         e |= up(slabs[s], &d_slabs[s]);
         for (size_t i = 0; i < slabs[s].size(); ++i)
-            for (int st = 0; st < slabs[s][i].count; st += 1024) slab_blocks[s].push_back(SlabBlock{(int)i, st});
+            for (int st = 0; st < slabs[s][i].count; st += 64) slab_blocks[s].push_back(SlabBlock{(int)i, st});
         e |= up(slab_blocks[s], &d_slab_blocks[s]);
     }
     return e ? MST_ERR_ALLOC : MST_OK;

@@ -142,8 +142,8 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
 def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True):
     """K different clips in ONE plan (mst_dims.clips = K) against (a) the oracle run clip by clip with
     gradients accumulating like train-model.py:126 and (b) the product's own one-clip plan run K times:
-    per-clip activations and losses are bit-identical; the summed gradient is bit-identical below 4 clips
-    (same reduction splits) and equal to rounding above."""
+    per-clip activations and losses are bit-identical; the summed gradient is equal to rounding (the order in
+    which per-clip partial sums meet differs)."""
     dims1 = make_dims(widths, C, R, T, unp)
     dimsK = make_dims(widths, C, R, T, unp, clips=K)
     # a plan picks its GEMM flavour from the clip count (K >= 4: f32 MFMA, else the latency kernel); the bitwise
@@ -181,10 +181,9 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
         for name in names:
             assert torch.equal(planK.view(name, clip=k), plan1.view(name)), (name, k)
         assert torch.equal(lossesK[k].nan_to_num(-1.), losses1.nan_to_num(-1.)), k
-    if K < 4:
-        assert torch.equal(gK, g1)
-    else:   # batched plans cut their weight-gradient reductions into fewer, longer k-splits / slabs: same sum, other order
-        assert rel(gK.cpu().numpy(), g1.cpu().numpy()) < 2e-6
+    # same partial sums, other association: the deferred slab reduction adds (clip, split) rows in four contiguous
+    # quarters, and batched plans cut their weight-gradient reductions into fewer, longer k-splits / slabs
+    assert rel(gK.cpu().numpy(), g1.cpu().numpy()) < 2e-6
     if not check_oracle:
         return
     # (a) oracle, clip by clip, grads accumulate
