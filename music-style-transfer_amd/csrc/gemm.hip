@@ -436,7 +436,7 @@ int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipSt
 // stage 2 sums in chunk order (deterministic; no float atomics).
 #define SEGRED_CHUNK 64
 // Stage 1, one lane per (destination row, chunk, column): the lane walks its chunk's reduced rows with an
-// odometer over the reduced dims (no divisions in the loop), four loads in flight, and adds them in row
+// odometer over the reduced dims (no divisions in the loop), eight loads in flight, and adds them in row
 // order.  No LDS, no barriers, and a workgroup always has 256 outputs' worth of work (a workgroup per
 // destination row left most lanes idle: the broadcast segments are 5-48 columns wide).
 __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, int members, int blocks_per_clip, Bases b) {
@@ -470,13 +470,15 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
     };
     float acc = 0.f;
     int rr = r_begin;
-    for (; rr + 4 <= r_end; rr += 4) {
-        const int64_t o0 = offset(); advance();
-        const int64_t o1 = offset(); advance();
-        const int64_t o2 = offset(); advance();
-        const int64_t o3 = offset(); advance();
-        const float v0 = src[o0], v1 = src[o1], v2 = src[o2], v3 = src[o3];
-        acc += v0; acc += v1; acc += v2; acc += v3;
+    for (; rr + 8 <= r_end; rr += 8) {                 // 8 loads in flight per round trip, added in row order
+        int64_t o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { o[q] = offset(); advance(); }
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[o[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
     }
     for (; rr < r_end; ++rr) { acc += src[offset()]; advance(); }
     if (d.nchunk == 1) b.p[SP_GRAD][d.dst_off + (int64_t)idx * d.dst_ld + w] += acc;
