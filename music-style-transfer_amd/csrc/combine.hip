@@ -26,9 +26,10 @@ __device__ __forceinline__ void block_sum_multi(float* vals, int nv, float (*par
     __syncthreads();
 }
 
-__device__ __forceinline__ int64_t elem_off(const CombineDesc& d, int64_t e) {
-    int64_t r = e / d.cols;
-    return r * d.ld + (e - r * d.cols);
+// element e of a rows x cols slice with row stride ld (32-bit index math: a slice has < 2^31 elements)
+__device__ __forceinline__ int64_t elem_off(const CombineDesc& d, int e) {
+    const unsigned r = (unsigned)e / (unsigned)d.cols;
+    return (int64_t)r * d.ld + (int)((unsigned)e - r * (unsigned)d.cols);
 }
 
 // part[blk*(MAXC+1) + c] = partial sum of squares of slice c over this workgroup's elements
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void combine_sumsq_kernel(const CombineDesc* _
     float acc[COMBINE_MAXC + 1];
 #pragma unroll
     for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)n; e += d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
 #pragma unroll
         for (int c = 0; c < COMBINE_MAXC; ++c) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void combine_apply_kernel(const CombineDesc* _
         tmp[d.stats_off + threadIdx.x] = (int)threadIdx.x < d.Cn ? nrm[threadIdx.x] : nrm[COMBINE_MAXC];
     const float S = nrm[COMBINE_MAXC];
     const int64_t n = (int64_t)d.rows * d.cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)n; e += d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         float acc = 0.f;
         for (int c = 0; c < d.Cn; ++c) acc += ws[d.x_off + (int64_t)c * d.cs + eo] * nrm[c];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void combine_bwd_reduce_kernel(const CombineDe
     float acc[COMBINE_MAXC + 1];
 #pragma unroll
     for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)n; e += d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         const float g = gr[d.gout_off + e];
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDes
     const float S = nc_s[d.Cn];
     const float bsum = coef[d.Cn];
     const int64_t n = (int64_t)d.rows * d.cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)d.nblk * 256) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)n; e += d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         const float g = gr[d.gout_off + e];
         for (int c = 0; c < d.Cn; ++c) {
@@ -153,15 +154,106 @@ __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDes
     }
 }
 
-int launch_combine_fwd(const CombineDesc* dev, int count, int max_nblk, Bases b, hipStream_t s) {
+// Small sites (<= COMBINE_SMALL elements per slice: the per-bar tensors, the style vector) need no cross-workgroup
+// re-sum: one workgroup per site does reduction and elementwise pass in ONE launch instead of two.
+__global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc d = descs[blockIdx.x];
+    __shared__ float nrm[COMBINE_MAXC + 1];
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    __shared__ float red[COMBINE_MAXC + 1];
+    float* ws = b.p[SP_WS];
+    float* tmp = b.p[SP_TMP];
+    const int n = d.rows * d.cols;
+    float acc[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int64_t eo = elem_off(d, e);
+#pragma unroll
+        for (int c = 0; c < COMBINE_MAXC; ++c) {
+            if (c < d.Cn) { const float v = ws[d.x_off + (int64_t)c * d.cs + eo]; acc[c] = fmaf(v, v, acc[c]); }
+        }
+    }
+    block_sum_multi(acc, d.Cn, part, red);
+    if ((int)threadIdx.x < d.Cn) nrm[threadIdx.x] = sqrtf(1.f + red[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float S = 0.f;
+        for (int c = 0; c < d.Cn; ++c) S += nrm[c];
+        nrm[COMBINE_MAXC] = S;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= d.Cn) tmp[d.stats_off + threadIdx.x] = (int)threadIdx.x < d.Cn ? nrm[threadIdx.x] : nrm[COMBINE_MAXC];
+    const float S = nrm[COMBINE_MAXC];
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int64_t eo = elem_off(d, e);
+        float a = 0.f;
+        for (int c = 0; c < d.Cn; ++c) a += ws[d.x_off + (int64_t)c * d.cs + eo] * nrm[c];
+        ws[d.out_off + e] = a / S;
+    }
+}
+
+__global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDesc* __restrict__ descs, Bases b) {
+    const CombineDesc d = descs[blockIdx.x];
+    __shared__ float coef[COMBINE_MAXC + 1];
+    __shared__ float nc_s[COMBINE_MAXC + 1];
+    __shared__ float part[4][COMBINE_MAXC + 1];
+    const float* ws = b.p[SP_WS];
+    float* gr = b.p[SP_GRAD];
+    const float* tmp = b.p[SP_TMP];
+    const int n = d.rows * d.cols;
+    float acc[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int64_t eo = elem_off(d, e);
+        const float g = gr[d.gout_off + e];
+#pragma unroll
+        for (int c = 0; c < COMBINE_MAXC; ++c) {
+            if (c < d.Cn) acc[c] = fmaf(g, ws[d.x_off + (int64_t)c * d.cs + eo], acc[c]);
+        }
+        acc[COMBINE_MAXC] = fmaf(g, ws[d.out_off + e], acc[COMBINE_MAXC]);
+    }
+    float vals[COMBINE_MAXC + 1];
+#pragma unroll
+    for (int c = 0; c < COMBINE_MAXC; ++c) vals[c] = acc[c];
+    vals[COMBINE_MAXC] = 0.f;
+#pragma unroll
+    for (int c = 0; c <= COMBINE_MAXC; ++c) if (c == d.Cn) vals[c] = acc[COMBINE_MAXC];
+    block_sum_multi(vals, d.Cn + 1, part, coef);
+    if ((int)threadIdx.x <= d.Cn) nc_s[threadIdx.x] = tmp[d.stats_off + threadIdx.x];       // n_c ..., S
+    __syncthreads();
+    const float S = nc_s[d.Cn];
+    const float bsum = coef[d.Cn];
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int64_t eo = elem_off(d, e);
+        const float g = gr[d.gout_off + e];
+        for (int c = 0; c < d.Cn; ++c) {
+            const float nc = nc_s[c];
+            const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
+            gr[d.gx_off + (int64_t)c * d.cs + eo] += g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+        }
+    }
+}
+
+// all_small: every site of the (merged) launch has <= COMBINE_SMALL elements per slice
+int launch_combine_fwd(const CombineDesc* dev, int count, int max_nblk, int all_small, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
+    if (all_small) {
+        hipLaunchKernelGGL(combine_small_fwd_kernel, dim3(count), dim3(256), 0, s, dev, b);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(combine_sumsq_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     hipLaunchKernelGGL(combine_apply_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();
 }
 
-int launch_combine_bwd(const CombineDesc* dev, int count, int max_nblk, Bases b, hipStream_t s) {
+int launch_combine_bwd(const CombineDesc* dev, int count, int max_nblk, int all_small, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
+    if (all_small) {
+        hipLaunchKernelGGL(combine_small_bwd_kernel, dim3(count), dim3(256), 0, s, dev, b);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(combine_bwd_reduce_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     hipLaunchKernelGGL(combine_bwd_apply_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();

@@ -119,6 +119,7 @@ struct LstmDesc {
 // ---- combine (style/model.py:796-815): out = sum_c x_c n_c / sum_c n_c
 #define COMBINE_MAXC 32
 #define COMBINE_MAXBLK 256
+#define COMBINE_SMALL 4096   // slices up to this many elements: reduction + elementwise pass in one single-workgroup launch
 struct CombineDesc {
     int32_t Cn, rows, cols, ld;  // each slice: rows x cols, row stride ld
     int64_t x_off, cs;           // slice c at x_off + c*cs                [SP_WS]
@@ -189,8 +190,8 @@ int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip,
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
-int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
-int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, Bases b, hipStream_t s);
+int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
+int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 // `count` descriptors of identical shape (the clips of a batched plan), blockIdx.y = descriptor
 int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);

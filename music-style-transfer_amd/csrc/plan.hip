@@ -524,11 +524,13 @@ struct mst_plan {
         CombineDesc c{}; c.Cn = Cn; c.rows = rows; c.cols = cols; c.ld = ld; c.x_off = x_off; c.cs = cs; c.out_off = out.off;
         c.stats_off = tmp(64); c.part_off = tmp(COMBINE_MAXBLK * (COMBINE_MAXC + 1));
         c.gx_off = x_off; c.gout_off = out.off;
+        if ((int64_t)rows * cols >= ((int64_t)1 << 31)) err = MST_ERR_UNSUPPORTED;      // the kernels index a slice with 32 bits
         int64_t nb = ((int64_t)rows * cols + 1023) / 1024;
         c.nblk = (int)(nb < 1 ? 1 : (nb > COMBINE_MAXBLK ? COMBINE_MAXBLK : nb));
+        const int large = (int64_t)rows * cols > COMBINE_SMALL ? 1 : 0;     // Step.b: 1 = needs the two-launch path
         Op op; op.stage = stage;
-        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, c.nblk, 0});
-        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, c.nblk, 0});
+        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, c.nblk, large});
+        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, c.nblk, large});
         combines.push_back(c);
         ops.push_back(op);
     }
@@ -1118,7 +1120,7 @@ extern "C" int32_t mst_plan_launch_count(const mst_plan* p, int32_t mask, int32_
     int n = 0;
     for (auto& s : p->list(mask, backward)) {
         if (!(s.stage & mask)) continue;
-        n += (s.kind == K_COMB_F || s.kind == K_COMB_B || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
+        n += (((s.kind == K_COMB_F || s.kind == K_COMB_B) && s.b != 0) || (s.kind == K_SEGRED && s.b > 0)) ? 2 : 1;
     }
     if (backward) for (int s = 0; s < 3; ++s) if ((mask >> s) & 1) n += 1;
     return n;
@@ -1141,8 +1143,8 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
     case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
-    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, b, st);
-    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, b, st);
+    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
+    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
     case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ROW_B: return launch_rowlin_bwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
