@@ -9,8 +9,8 @@
 // side) are fused into the tile load / epilogue.
 //
 // Tiling: 32x32 outputs x KD-deep k-tile (KD = 32 / 64 / 128 by the descriptor's k range) per
-// 512-thread workgroup; the eight waves split the k-tile (in-block split-K), 4x4 register micro-tile per lane, LDS tiles stored k-major (+4 pad,
-// float4 fragment reads).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
+// 1024-thread workgroup; the sixteen waves split the k-tile (in-block split-K), each running its k rows through
+// v_mfma_f32_32x32x2_f32 (one 32x32 accumulator tile per wave), LDS tiles stored k-major (+4 pad).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
 // tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
 // Independent GEMMs share one launch: the 1-D grid is the concatenation of every member's
 // (tile, k-split) workgroups; k-splits of weight gradients write deterministic slabs that are
@@ -117,15 +117,15 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     const int k0 = split * kchunk;
     const int k1 = min(d.K, k0 + kchunk);
     const int wv = tid >> 6, lane = tid & 63;
-    const int ty = lane >> 3, tx = lane & 7;
     const int a_act = (AK == OPK_ACTGRAD) ? d.A.act : ACT_LEAKY;
     const int a_tr = d.A.transposed;
     const int b_ones = (BKIND == OPK_DENSE || BKIND == OPK_IM2COL) ? d.B.ones_at : -1;   // bias-gradient column of B
-    float acc[4][4];
+    // this wave's 32x32 partial tile over its k rows, on the matrix cores: v_mfma_f32_32x32x2_f32 is exact f32 (a k-ordered
+    // fmaf chain).  Lane l feeds A[row l&31][k l>>5], B[k l>>5][col l&31]; register r holds C[(r&3) + 8(r>>2) + 4(l>>5)][l&31].
+    typedef float acc_f32x16 __attribute__((ext_vector_type(16)));
+    acc_f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     constexpr int NT = GEMM_THREADS, NW = NT / 64;
     constexpr int NL = GEMM_BM * KD / NT;            // tile elements per lane and operand (2 / 4 / 8)
@@ -172,15 +172,9 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
         __syncthreads();
         if (kt + KD < k1) GEMM_ISSUE(kt + KD)                // next tile's loads fly under this tile's FMAs
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const int k = wv * KW + kk;
-            float a[4], bb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; bb[i] = Bs[k][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+        for (int kk = 0; kk < KW; kk += 2) {
+            const int k = wv * KW + kk + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][lane & 31], Bs[k][lane & 31], acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -192,9 +186,8 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
     // sum the waves' partial tiles (fixed order) and run the epilogue
     float* red = &As[0][0];                          // NW x 32 x 32 floats fit in the A+B tile storage (contiguous)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[wv * (GEMM_BM * GEMM_BN) + (ty * 4 + i) * GEMM_BN + tx * 4 + j] = acc[i][j];
+    for (int r = 0; r < 16; ++r)
+        red[wv * (GEMM_BM * GEMM_BN) + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * GEMM_BN + (lane & 31)] = acc[r];
     __syncthreads();
     float* cbase = b.p[d.out.space] + d.out.off;
     const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
