@@ -226,7 +226,7 @@ struct mst_plan {
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     int err = 0;
     int nlanes = 1;
-    int mfma = 0;                 // GEMM flavour of this plan: 1 = f32 MFMA 64x64 tiles (batched, FLOP-bound plans), 0 = latency kernel
+    int mfma = 0;                 // GEMM tiling of this plan: 1 = 64x64 tiles (batched, FLOP-bound plans), 0 = 32x32 split-K tiles (latency)
     struct LaneCtx { std::vector<hipStream_t> side; std::vector<hipEvent_t> ev; hipEvent_t start = nullptr; };
     mutable std::map<std::pair<hipStream_t, int>, LaneCtx> lane_ctx;   // per (caller stream, pass): side streams + step events
                                                                         // (an event is recorded once per capture)
@@ -1027,10 +1027,12 @@ void mst_plan::schedule() {
     // experimental, default off: on ROCm 7.2 the cross-stream graph edges cost more than the overlap returns
     // (815 -> 870 it/s with 2 lanes, 741 with 4; nested inside another capture fork hipStreamEndCapture crashes)
     nlanes = env ? atoi(env) : 1;
-    // one clip per launch is latency-bound (the 32x32 split-K kernel); from a few clips per launch on the GEMMs are
-    // FLOP-bound and go to the matrix cores.  MST_GEMM=mfma|valu overrides (experiments, tests).
+    // Two GEMM tilings, both on v_mfma_f32_32x32x2_f32: few clips per launch are latency-bound and want many small
+    // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about a dozen clips per launch on
+    // the launches fill the chip and the 64x64-tile kernel wins (measured crossover between 8 and 16 clips: 3060 vs
+    // 2950 clip-it/s at 8, 3930 vs 4370 at 16).  MST_GEMM=mfma|valu forces the 64x64 / 32x32 tiling (experiments, tests).
     const char* ge = getenv("MST_GEMM");
-    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 4);
+    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 12);
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
     std::vector<Step> fwd, bwd;
