@@ -296,7 +296,7 @@ def main():
                                     'step, Adam+StepLR every iter_size steps',
                            clips_per_gpu=B, iter_size=iter_size, hip_graph=graph_pair is not None,
                            accumulation=('batched plan, %d clips per launch' % K) if batched else '2 concurrent streams',
-                           launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 5,
+                           launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 4,      # + memset, 3 loss kernels
                            parallelism=f'dp{world} ({"RCCL" if args.backend == "nccl" else args.backend} all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
                            device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))
     if rank == 0:

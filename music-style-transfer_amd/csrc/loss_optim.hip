@@ -147,13 +147,18 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
                                                        const float* il, const float* it, int ni,
                                                        const float* mlg, const float* mt,
                                                        const float* bp, const float* bt, int normalize,
-                                                       float* losses, float* saved, LossBatch lb) {
+                                                       float* losses, float* saved, LossBatch lb,
+                                                       float* gl_onehot, float* losses_out) {
     __shared__ float sums[N_TAPE_IN];
     const int tid = threadIdx.x;
     {
         const int64_t k = blockIdx.y;
         scratch += k * lb.tmp; il += k * lb.ws; it += k * lb.ws; mlg += k * lb.ws; mt += k * lb.ws; bp += k * lb.ws;
         bt += k * lb.ws; losses += k * lb.ws; saved += k * lb.ws;
+        // train-iteration extras (null for the stand-alone entry point): the upstream gradient of loss.backward() — one-hot
+        // on the total — and a dense copy of the leaves for the caller, written here instead of by two more launches
+        if (gl_onehot) gl_onehot += k * lb.ws;
+        if (losses_out) losses_out += k * MST_N_LOSSES;
     }
     // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; tape inputs 0..6 are the pitched tensor's,
     // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}.  Lanes stride over the per-workgroup partials,
@@ -220,7 +225,12 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
     leaf[MST_L_TOTAL] = d_qmean2(leaf[MST_L_CH_TOTAL], leaf[MST_L_SI_TOTAL]);
 #pragma unroll
     for (int k = 0; k < MST_N_LOSSES; ++k) {
-        if (tid == 0) losses[k] = present[k] ? leaf[k].v : __builtin_nanf("");
+        if (tid == 0) {
+            const float v = present[k] ? leaf[k].v : __builtin_nanf("");
+            losses[k] = v;
+            if (losses_out) losses_out[k] = v;
+            if (gl_onehot) gl_onehot[k] = k == MST_L_TOTAL ? 1.f : 0.f;
+        }
         saved[SAVED_J + k * N_TAPE_IN + tid] = present[k] ? leaf[k].d : 0.f;
     }
 }
@@ -305,7 +315,7 @@ static int blocks_for(int64_t n) {
 
 int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt, int normalize,
-                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s) {
+                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s, float* gl_onehot, float* losses_out) {
     if (!pp || !pt || !il || !it || !mlg || !mt || !bp || !bt || !losses || !saved || !scratch || np <= 0 || lb.clips < 1)
         return MST_ERR_ARG;
     const int has_u = (up && ut && nu > 0) ? 1 : 0;
@@ -313,7 +323,7 @@ int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* 
     hipLaunchKernelGGL(loss_partials_kernel, dim3(nbp + nbu, lb.clips), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
                        has_u ? nu : (int64_t)0, nbu, scratch, lb);
     hipLaunchKernelGGL(loss_tail_kernel, dim3(1, lb.clips), dim3(64), 0, s, (const float*)scratch, nbp, nbu, has_u, il, it,
-                       ni, mlg, mt, bp, bt, normalize, losses, saved, lb);
+                       ni, mlg, mt, bp, bt, normalize, losses, saved, lb, gl_onehot, losses_out);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
@@ -336,7 +346,7 @@ extern "C" int32_t mst_total_loss_fwd(const float* pp, const float* pt, int64_t 
                                       const float* mt, const float* bp, const float* bt, int32_t normalize,
                                       float* losses, float* saved, float* scratch, mst_stream stream) {
     return loss_fwd_batched(pp, pt, np, up, ut, nu, il, it, (int)ni, mlg, mt, bp, bt, (int)normalize, losses, saved, scratch,
-                            ONE_CLIP, (hipStream_t)stream);
+                            ONE_CLIP, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int32_t mst_total_loss_bwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,

@@ -201,7 +201,9 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count,
 struct LossBatch { int32_t clips; int64_t ws, grad, tmp, ext0, ext1; };
 int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt, int normalize,
-                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s);
+                     float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s,
+                     float* gl_onehot /* nullable: [clips x ws stride] one-hot on the total */,
+                     float* losses_out /* nullable: clips x MST_N_LOSSES dense copy */);
 int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
                      const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,

@@ -1251,16 +1251,6 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     return MST_OK;
 }
 
-__global__ void onehot_kernel(float* p, int n, int hot, int64_t clip_stride) {
-    const int i = threadIdx.x;
-    if (i < n) p[(int64_t)blockIdx.x * clip_stride + i] = i == hot ? 1.f : 0.f;
-}
-
-__global__ void collect_kernel(float* dst, const float* src, int n, int64_t clip_stride) {
-    const int i = threadIdx.x;
-    if (i < n) dst[(int64_t)blockIdx.x * n + i] = src[(int64_t)blockIdx.x * clip_stride + i];
-}
-
 extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
                                        const float* pitched, const float* unpitched, float* losses, mst_stream stream) {
     if (!p || !params || !gparams || !ws || !pitched) return MST_ERR_ARG;
@@ -1279,9 +1269,8 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     e = loss_fwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
                          nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
                          ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), 1, ws + p->t_losses.off,
-                         ws + p->t_saved.off, lscratch, lb, st);
+                         ws + p->t_saved.off, lscratch, lb, st, ws + p->t_gl.off, losses);
     if (e) return e;
-    hipLaunchKernelGGL(onehot_kernel, dim3(K), dim3(64), 0, st, ws + p->t_gl.off, (int)MST_N_LOSSES, (int)MST_L_TOTAL, p->act_top);
     e = loss_bwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
                          nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
                          ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off,
@@ -1290,8 +1279,6 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     if (e) return e;
     e = mst_backward(p, MST_STAGE_ALL, params, gparams, ws, pitched, unpitched, stream);
     if (e) return e;
-    if (losses) hipLaunchKernelGGL(collect_kernel, dim3(K), dim3(64), 0, st, losses, (const float*)(ws + p->t_losses.off),
-                                   (int)MST_N_LOSSES, p->act_top);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
