@@ -40,6 +40,10 @@ __device__ __forceinline__ float act_bwd(int act, float y, int col) {
 // k-tile, issue all loads unconditionally (padding / bias-ones columns read a constant from
 // memory instead of branching) so they fly under the current tile's FMAs, consume one tile later.
 typedef const MST_GLOBAL_AS float* gcptr;
+// LDS tiles are k-major, row stride = tile edge + GEMM_PAD floats.  An ODD stride makes the k-fast tile stores (lanes walk
+// k: bank = k * stride mod 32) conflict-free; the MFMA fragment reads (lanes walk the row) are conflict-free at any stride.
+// (PMC with the old +4 pad: 2 bank-conflict cycles per LDS instruction in the 64x64 kernel.)
+#define GEMM_PAD 1
 
 // Element offset of operand(i, j) — branch-free; `ok` is cleared for im2col padding taps.
 // (i, j) = (m, k) for the A operand and (k, n) for the B operand.
@@ -97,7 +101,7 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
 
 template <int AK, int BKIND, int OK, int AKF, int BKF, int KD>
 __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
-                                          float (*As)[GEMM_BM + 4], float (*Bs)[GEMM_BN + 4]) {
+                                          float (*As)[GEMM_BM + GEMM_PAD], float (*Bs)[GEMM_BN + GEMM_PAD]) {
     // 32x32 output tile per workgroup, 128-deep k-tile: wave w owns k rows [32w, 32w+32) of the
     // tile (in-block split-K), so the dependent k chain is K/128 steps and small problems still
     // spread over many workgroups; the four partial tiles are summed through LDS at the end.
@@ -218,7 +222,7 @@ typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int AK, int BKIND, int OK, int AKF, int BKF>
 __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
-                                               float (*As)[MF_BM + 4], float (*Bs)[MF_BN + 4]) {
+                                               float (*As)[MF_BM + GEMM_PAD], float (*Bs)[MF_BN + GEMM_PAD]) {
     const int tid = threadIdx.x;
     const int M = d.M, N = d.N;
     const int tiles_n = (N + MF_BN - 1) / MF_BN;
@@ -306,9 +310,9 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
 }
 
 __global__ __launch_bounds__(MF_THREADS) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
-    __shared__ float smem[2 * MF_KD * (MF_BM + 4)];
-    float (*As)[MF_BM + 4] = reinterpret_cast<float (*)[MF_BM + 4]>(smem);
-    float (*Bs)[MF_BN + 4] = reinterpret_cast<float (*)[MF_BN + 4]>(smem + MF_KD * (MF_BM + 4));
+    __shared__ float smem[2 * MF_KD * (MF_BM + GEMM_PAD)];
+    float (*As)[MF_BM + GEMM_PAD] = reinterpret_cast<float (*)[MF_BM + GEMM_PAD]>(smem);
+    float (*Bs)[MF_BN + GEMM_PAD] = reinterpret_cast<float (*)[MF_BN + GEMM_PAD]>(smem + MF_KD * (MF_BM + GEMM_PAD));
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
     int y = 0;
     while (y + 1 < count && lb >= starts[y + 1]) ++y;          // starts[]: one cache line, not one descriptor per probe
@@ -337,10 +341,10 @@ int gemm_tile_edge(int mfma) { return mfma ? MF_BM : GEMM_BM; }
 // all small Linears of one dependency level — into a single launch.
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
     // A tile | B tile; the final reduce overlays the whole block with one 32x32 partial tile per wave
-    constexpr int TILE_F = GEMM_BK * (GEMM_BM + 4), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
+    constexpr int TILE_F = GEMM_BK * (GEMM_BM + GEMM_PAD), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
     __shared__ float smem[(2 * TILE_F > RED_F) ? 2 * TILE_F : RED_F];
-    float (*As)[GEMM_BM + 4] = reinterpret_cast<float (*)[GEMM_BM + 4]>(smem);
-    float (*Bs)[GEMM_BN + 4] = reinterpret_cast<float (*)[GEMM_BN + 4]>(smem + TILE_F);
+    float (*As)[GEMM_BM + GEMM_PAD] = reinterpret_cast<float (*)[GEMM_BM + GEMM_PAD]>(smem);
+    float (*Bs)[GEMM_BN + GEMM_PAD] = reinterpret_cast<float (*)[GEMM_BN + GEMM_PAD]>(smem + TILE_F);
     // flat 1-D grid: clip-major; inside a clip's block range member y owns [blk_begin, blk_begin + tiles * ksplit)
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
     int y = 0;
