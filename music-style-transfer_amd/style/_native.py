@@ -4,6 +4,7 @@ The product always loads `music-style-transfer_amd/libmst_amd.so` (hipcc, gfx950
 if it is missing: there is no CPU fallback.  Tests may bind another build of the *same* C ABI
 (the hipsim interpreter build of the same .hip sources) by passing an explicit path.
 """
+import collections
 import ctypes as C
 import os
 
@@ -97,7 +98,10 @@ class Native:
         for name, (res, args) in _SIGS.items():
             fn = getattr(self.lib, name)      # raises AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
-        self._plans = {}
+        # plans (schedule + descriptors + a workspace of 100 MB per clip and up) are cached per (dims, device); training on
+        # real songs sees a new (C, R) nearly every iteration, so the cache is a small LRU, not a dict that grows forever
+        self._plans = collections.OrderedDict()
+        self._plan_cap = int(os.environ.get('MST_PLAN_CACHE', '16'))
 
     # ---- parameter layout
     def param_table(self, dims):
@@ -117,9 +121,13 @@ class Native:
 
     def plan(self, dims, device):
         key = (dims.key(), str(device))
-        if key not in self._plans:
-            self._plans[key] = Plan(self, dims, device)
-        return self._plans[key]
+        if key in self._plans:
+            self._plans.move_to_end(key)
+            return self._plans[key]
+        plan = self._plans[key] = Plan(self, dims, device)
+        while len(self._plans) > max(1, self._plan_cap):
+            self._plans.popitem(last=False)       # the Plan (and its workspace) dies when its last autograd user lets go
+        return plan
 
 
 def current_stream(device):
