@@ -219,6 +219,7 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 #define MF_KD 32
 #define MF_THREADS 256
 typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float mf_f4u __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load that only needs 4-byte alignment
 
 template <int AK, int BKIND, int OK, int AKF, int BKF>
 __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
@@ -246,31 +247,74 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
     constexpr int NT = MF_THREADS;
     constexpr int NL = MF_BM * MF_KD / NT;           // 8 tile elements per lane and operand
     float va[NL], ya[NL], vb[NL];
-#define A_ROW(i) (AKF ? (tid / MF_KD) + (NT / MF_KD) * (i) : (tid & (MF_BM - 1)))
-#define A_KL(i) (AKF ? (tid % MF_KD) : (tid / MF_BM) + (NT / MF_BM) * (i))
-#define B_ROW(i) (BKF ? (tid / MF_KD) + (NT / MF_KD) * (i) : (tid & (MF_BN - 1)))
-#define B_KL(i) (BKF ? (tid % MF_KD) : (tid / MF_BN) + (NT / MF_BN) * (i))
+    // Slot i = 4*g + j of a lane: element j of its group g.  A group is 4 consecutive elements along the operand's
+    // memory-contiguous direction (k when the *KF flag is set, the row index otherwise), so a dense / activation-gradient
+    // operand is fetched with ONE 16-byte load per group instead of four 4-byte loads (the kernel is load-latency bound:
+    // PMC shows its waves parked on memory 60 % of the time).  A group that crosses M / N / k1, holds the bias-ones
+    // column or is not unit-stride falls back to four predicated scalar loads; im2col / permuted-weight operands always do.
+    // (operands that are never vectorised keep the lane-contiguous element order: consecutive lanes, consecutive addresses)
+#define VROW(KF, g, j, TBX) ((KF) ? (tid + NT * (g)) / (MF_KD / 4) : ((tid + NT * (g)) % ((TBX) / 4)) * 4 + (j))
+#define VKL(KF, g, j, TBX) ((KF) ? ((tid + NT * (g)) % (MF_KD / 4)) * 4 + (j) : (tid + NT * (g)) / ((TBX) / 4))
+#define SROW(KF, i, TBX) ((KF) ? (tid / MF_KD) + (NT / MF_KD) * (i) : (tid & ((TBX) - 1)))
+#define SKL(KF, i, TBX) ((KF) ? (tid % MF_KD) : (tid / (TBX)) + (NT / (TBX)) * (i))
+#define A_ROW(i) (VEC_A ? VROW(AKF, (i) >> 2, (i) & 3, MF_BM) : SROW(AKF, i, MF_BM))
+#define A_KL(i) (VEC_A ? VKL(AKF, (i) >> 2, (i) & 3, MF_BM) : SKL(AKF, i, MF_BM))
+#define B_ROW(i) (VEC_B ? VROW(BKF, (i) >> 2, (i) & 3, MF_BN) : SROW(BKF, i, MF_BN))
+#define B_KL(i) (VEC_B ? VKL(BKF, (i) >> 2, (i) & 3, MF_BN) : SKL(BKF, i, MF_BN))
+    constexpr bool VEC_A = AK == OPK_DENSE || AK == OPK_ACTGRAD;
+    constexpr bool VEC_B = BKIND == OPK_DENSE;
 #define MF_ISSUE(KT)                                                                                       \
     {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                   \
-            const int m = tm * MF_BM + A_ROW(i), ka = (KT) + A_KL(i);                                      \
-            bool oka = (m < M) & (ka < k1);                                                                \
-            int ia = off_of<AK>(d.A, m, ka, oka);                                                          \
-            ia = oka ? ia : 0;                                                                             \
-            const float x = baseA[(unsigned)ia];                                                           \
-            if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                       \
-                const float y = baseA2[(unsigned)ia];                                                      \
-                const int col = (AK == OPK_ACTGRAD) ? (a_tr ? m : ka) : 0;                                 \
-                ya[i] = act_bwd(a_act, y, col);                                                            \
-            } else ya[i] = 1.f;                                                                            \
-            va[i] = oka ? x : 0.f;                                                                         \
-            const int n = tn * MF_BN + B_ROW(i), kb = (KT) + B_KL(i);                                      \
-            bool okb = (n < N) & (kb < k1);                                                                \
-            const bool one = okb & (n == b_ones);                                                          \
-            int ib = off_of<BKIND>(d.B, kb, n, okb);                                                       \
-            ib = (okb & !one) ? ib : 0;                                                                    \
-            const float w = baseB[(unsigned)ib];                                                           \
-            vb[i] = one ? 1.f : (okb ? w : 0.f);                                                           \
+        _Pragma("unroll") for (int g = 0; g < NL / 4; ++g) {                                               \
+            int ia[4], ib[4];                                                                              \
+            bool oka[4], okb[4], one[4];                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                const int i = 4 * g + j;                                                                   \
+                const int m = tm * MF_BM + A_ROW(i), ka = (KT) + A_KL(i);                                  \
+                oka[j] = (m < M) & (ka < k1);                                                              \
+                ia[j] = off_of<AK>(d.A, m, ka, oka[j]);                                                    \
+                ia[j] = oka[j] ? ia[j] : 0;                                                                \
+                if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                   \
+                    /* derivative column index; the value itself is applied below */                      \
+                }                                                                                          \
+                const int n = tn * MF_BN + B_ROW(i), kb = (KT) + B_KL(i);                                  \
+                okb[j] = (n < N) & (kb < k1);                                                              \
+                one[j] = okb[j] & (n == b_ones);                                                           \
+                ib[j] = off_of<BKIND>(d.B, kb, n, okb[j]);                                                 \
+                ib[j] = (okb[j] & !one[j]) ? ib[j] : 0;                                                    \
+            }                                                                                              \
+            float xa[4], y4[4], xb[4];                                                                     \
+            const bool veca = VEC_A && oka[0] && oka[3] && (ia[3] - ia[0] == 3);                           \
+            if (veca) {                                                                                    \
+                const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (unsigned)ia[0]);  \
+                xa[0] = t[0]; xa[1] = t[1]; xa[2] = t[2]; xa[3] = t[3];                            \
+                if constexpr (AK == OPK_ACTGRAD) {                                                         \
+                    const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA2 + (unsigned)ia[0]); \
+                    y4[0] = u[0]; y4[1] = u[1]; y4[2] = u[2]; y4[3] = u[3];                        \
+                }                                                                                          \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+                    xa[j] = baseA[(unsigned)ia[j]];                                                        \
+                    if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) y4[j] = baseA2[(unsigned)ia[j]]; \
+                }                                                                                          \
+            }                                                                                              \
+            const bool vecb = VEC_B && okb[0] && okb[3] && (ib[3] - ib[0] == 3) && !(one[0] | one[1] | one[2] | one[3]); \
+            if (vecb) {                                                                                    \
+                const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (unsigned)ib[0]);  \
+                xb[0] = t[0]; xb[1] = t[1]; xb[2] = t[2]; xb[3] = t[3];                            \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) xb[j] = baseB[(unsigned)ib[j]];              \
+            }                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                const int i = 4 * g + j;                                                                   \
+                if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                   \
+                    const int m = tm * MF_BM + A_ROW(i), ka = (KT) + A_KL(i);                              \
+                    const int col = (AK == OPK_ACTGRAD) ? (a_tr ? m : ka) : 0;                             \
+                    ya[i] = act_bwd(a_act, y4[j], col);                                                    \
+                } else ya[i] = 1.f;                                                                        \
+                va[i] = oka[j] ? xa[j] : 0.f;                                                              \
+                vb[i] = one[j] ? 1.f : (okb[j] ? xb[j] : 0.f);                                             \
+            }                                                                                              \
         }                                                                                                  \
     }
     if (k0 < k1) MF_ISSUE(k0)
@@ -298,6 +342,10 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
 #undef A_KL
 #undef B_ROW
 #undef B_KL
+#undef VROW
+#undef VKL
+#undef SROW
+#undef SKL
     if (!live) return;
     float* cbase = b.p[d.out.space] + d.out.off;
     const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
