@@ -1028,11 +1028,11 @@ void mst_plan::schedule() {
     // (815 -> 870 it/s with 2 lanes, 741 with 4; nested inside another capture fork hipStreamEndCapture crashes)
     nlanes = env ? atoi(env) : 1;
     // Two GEMM tilings, both on v_mfma_f32_32x32x2_f32: few clips per launch are latency-bound and want many small
-    // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about a dozen clips per launch on
-    // the launches fill the chip and the 64x64-tile kernel wins (measured crossover between 8 and 16 clips: 3060 vs
-    // 2950 clip-it/s at 8, 3930 vs 4370 at 16).  MST_GEMM=mfma|valu forces the 64x64 / 32x32 tiling (experiments, tests).
+    // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about six clips per launch on
+    // the launches fill the chip and the 64x64-tile kernel (16-byte tile loads) wins (measured crossover between 4 and 8
+    // clips: 2475 vs 2306 clip-it/s at 4, 3060 vs 3340 at 8).  MST_GEMM=mfma|valu forces the 64x64 / 32x32 tiling (experiments, tests).
     const char* ge = getenv("MST_GEMM");
-    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 12);
+    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 6);
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
     std::vector<Step> fwd, bwd;

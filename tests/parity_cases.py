@@ -146,7 +146,7 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     which per-clip partial sums meet differs)."""
     dims1 = make_dims(widths, C, R, T, unp)
     dimsK = make_dims(widths, C, R, T, unp, clips=K)
-    # a plan picks its GEMM tiling from the clip count (K >= 12: 64x64 tiles, else 32x32 split-K); the bitwise
+    # a plan picks its GEMM tiling from the clip count (K >= 6: 64x64 tiles, else 32x32 split-K); the bitwise
     # comparison needs both plans on the same one
     old_flavour = os.environ.get('MST_GEMM')
     os.environ['MST_GEMM'] = 'mfma' if K >= 4 else 'valu'

@@ -43,7 +43,7 @@ def test_batched_clips_equal_sequential_iterations(C, R, T, unp, K):
 
 
 def test_batched_clips_on_the_mfma_gemm():
-    # batch_case forces the 64x64-tile GEMM for K >= 4 (the product switches at 12 clips per launch)
+    # batch_case forces the 64x64-tile GEMM for K >= 4 (the product switches at 6 clips per launch)
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4)
 
 
