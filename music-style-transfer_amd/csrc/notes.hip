@@ -233,10 +233,17 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
     constexpr int KL = PSA_HW + ML;
     constexpr int NW = NPF * KL + NPF;                 // linear.weight (5 x KL) then linear.bias (5)
     constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW;
-    static_assert(NW <= 256, "role count exceeds the workgroup");
+    constexpr int NTP = NPN + 4;                       // note-major rows, 16-byte aligned, 8 lanes of a b128 read span all banks
+    static_assert(NW <= 256 && NPN % 4 == 0, "role count exceeds the workgroup");
     __shared__ float w_s[NPF * KL];
     __shared__ float lo_s[NLO], ld_s[NLD];
-    __shared__ float dz_s[NPN][NPF], h_s[NPN][PSA_HW], dh_s[NPN][PSA_HW], ml_s[NPN][ML];
+    // per-note vectors are staged TRANSPOSED ([feature][note]): the note phase writes lane-contiguous, and a role lane
+    // reads four notes of its two operands with two 16-byte LDS reads per four FMAs (it was two 4-byte reads per FMA:
+    // PMC showed one LDS instruction per 1.8 VALU instructions)
+    __shared__ __attribute__((aligned(16))) float dz_t[NPF][NTP];
+    __shared__ __attribute__((aligned(16))) float h_t[PSA_HW][NTP];
+    __shared__ __attribute__((aligned(16))) float ml_t[ML][NTP];
+    __shared__ float dh_t[PSA_HW][NTP];
     const int tid = threadIdx.x;
     const float* par = b.p[SP_PAR];
     for (int i = tid; i < NPF * KL; i += 256) w_s[i] = par[d.wl_off + i];
@@ -256,9 +263,12 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
         if (tid + 256 < NOD) od1 = ws[d.deg_off + row * NLD + (tid + 256 - NLO)];
     };
     if ((int)blockIdx.x < QF) fetch_od((int64_t)blockIdx.x);
+    // this lane's role: element (ri, rj) of linear.weight, or bias element ri
+    const int ri = tid < NPF * KL ? tid / KL : tid - NPF * KL;
+    const int rj = tid < NPF * KL ? tid % KL : -1;
     for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < NPN * ML; i += 256) ml_s[i / ML][i % ML] = ws[d.ml_off + (int64_t)qf * NPN * ML + i];
+        for (int i = tid; i < NPN * ML; i += 256) ml_t[i % ML][i / ML] = ws[d.ml_off + (int64_t)qf * NPN * ML + i];
         float gml[KQ];
 #pragma unroll
         for (int k = 0; k < KQ; ++k) gml[k] = 0.f;
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                     const float y = ws[d.out_off + pos * NPF + i];
                     const float dy = b.p[SP_GRAD][d.g_out_off + pos * NPF + i];
                     dz[i] = dy * (i == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y));
-                    if (wv == 0) dz_s[n][i] = dz[i];
+                    if (wv == 0) dz_t[i][n] = dz[i];
                 }
 #pragma unroll
                 for (int jj = 0; jj < JQ; ++jj) {
@@ -288,8 +298,8 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                         float g = 0.f;
 #pragma unroll
                         for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + j], g);
-                        h_s[n][j] = h;
-                        dh_s[n][j] = g * dlrelu(h);
+                        h_t[j][n] = h;
+                        dh_t[j][n] = g * dlrelu(h);
                     }
                 }
 #pragma unroll
@@ -305,15 +315,18 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
             }
             __syncthreads();
             if (tid < NW) {
+                const float4* pa = reinterpret_cast<const float4*>(dz_t[ri]);
                 float a = 0.f;
-                if (tid >= NPF * KL) {
-                    const int i = tid - NPF * KL;
-                    // (unrolled: 8+ independent LDS reads in flight instead of one read latency per note)
-                    _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a += dz_s[m][i];
+                if (rj < 0) {
+#pragma unroll
+                    for (int m4 = 0; m4 < NPN / 4; ++m4) { const float4 x = pa[m4]; a += x.x; a += x.y; a += x.z; a += x.w; }
                 } else {
-                    const int i = tid / KL, jj = tid % KL;
-                    if (jj < PSA_HW) { _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], h_s[m][jj], a); }
-                    else { _Pragma("unroll 8") for (int m = 0; m < NPN; ++m) a = fmaf(dz_s[m][i], ml_s[m][jj - PSA_HW], a); }
+                    const float4* pb = reinterpret_cast<const float4*>(rj < PSA_HW ? h_t[rj] : ml_t[rj - PSA_HW]);
+#pragma unroll
+                    for (int m4 = 0; m4 < NPN / 4; ++m4) {
+                        const float4 x = pa[m4], y = pb[m4];
+                        a = fmaf(x.x, y.x, a); a = fmaf(x.y, y.y, a); a = fmaf(x.z, y.z, a); a = fmaf(x.w, y.w, a);
+                    }
                 }
                 wacc += a;
             }
@@ -322,12 +335,12 @@ __global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __r
                 if (r < NLO) {
                     const int oo = r / PSA_HW, j = r % PSA_HW;
 #pragma unroll
-                    for (int q = 0; q < NDEG; ++q) a += dh_s[oo * NDEG + q][j];
+                    for (int q = 0; q < NDEG; ++q) a += dh_t[j][oo * NDEG + q];
                     b.p[SP_GRAD][d.g_oct_off + row * NLO + r] = a;      // sole writer of this row: store, not read-modify-write
                 } else {
                     const int q = (r - NLO) / PSA_HW, j = (r - NLO) % PSA_HW;
 #pragma unroll
-                    for (int oo = 0; oo < NOCT; ++oo) a += dh_s[oo * NDEG + q][j];
+                    for (int oo = 0; oo < NOCT; ++oo) a += dh_t[j][oo * NDEG + q];
                     b.p[SP_GRAD][d.g_deg_off + row * NLD + (r - NLO)] = a;
                 }
             }
