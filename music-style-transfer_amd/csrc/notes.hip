@@ -74,7 +74,12 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
     static_assert(NW <= 256 && (NOCT + NDEG) * W <= 256, "role count exceeds the workgroup");
     __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL];
     __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
-    __shared__ float gm_s[NPN][W], god_s[NPN][W], gc_s[NPN][CW], cat_s[NPN][KL], x_s[NPN][NPF];
+    // per-note vectors staged transposed ([feature][note], 16-byte aligned rows): lane-contiguous writes in the note phase,
+    // two 16-byte LDS reads per four FMAs in the role sums (see psa_notes_bwd_kernel)
+    constexpr int NTP = NPN + 4;
+    static_assert(NPN % 4 == 0, "notes per group");
+    __shared__ __attribute__((aligned(16))) float gm_t[W][NTP], gc_t[CW][NTP], cat_t[KL][NTP], x_t[NPF][NTP];
+    __shared__ float god_t[W][NTP];
     const int tid = threadIdx.x;
     const float* par = b.p[SP_PAR];
     for (int i = tid; i < CW * NPF; i += 256) wc_s[i] = par[d.wc_off + i];
@@ -105,9 +110,9 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
                 for (int j = 0; j < W; ++j) gm[j] = b.p[SP_GRAD][d.g_out_off + pos * W + j] * dlrelu(ws[d.out_off + pos * W + j]);
                 if (wv == 0) {
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) x_s[n][i] = x5[i];
+                    for (int i = 0; i < NPF; ++i) x_t[i][n] = x5[i];
 #pragma unroll
-                    for (int j = 0; j < W; ++j) gm_s[n][j] = gm[j];
+                    for (int j = 0; j < W; ++j) gm_t[j][n] = gm[j];
                 }
 #pragma unroll
                 for (int ii = 0; ii < IQ; ++ii) {
@@ -126,26 +131,37 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
 #pragma unroll
                         for (int j = 0; j < W; ++j) g = fmaf(gm[j], wl_s[j * KL + i], g);
                         g *= dlrelu(c);
-                        cat_s[n][i] = c;
-                        if (i < W) god_s[n][i] = g; else gc_s[n][i - W] = g;
+                        cat_t[i][n] = c;
+                        if (i < W) god_t[i][n] = g; else gc_t[i - W][n] = g;
                     }
                 }
             }
             __syncthreads();
             if (tid < NW) {
-                float a = 0.f;
+                // a role lane sums pa[n] (* pb[n]) over the 56 notes, four notes per pair of 16-byte reads
+                const float4* pa;
+                const float4* pb = nullptr;
                 if (tid >= R_BL) {
-                    const int j = tid - R_BL;
-                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a += gm_s[n][j];
+                    pa = reinterpret_cast<const float4*>(gm_t[tid - R_BL]);
                 } else if (tid >= R_WL) {
-                    const int j = (tid - R_WL) / KL, i = (tid - R_WL) % KL;
-                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a = fmaf(gm_s[n][j], cat_s[n][i], a);
+                    pa = reinterpret_cast<const float4*>(gm_t[(tid - R_WL) / KL]);
+                    pb = reinterpret_cast<const float4*>(cat_t[(tid - R_WL) % KL]);
                 } else if (tid >= R_BC) {
-                    const int k = tid - R_BC;
-                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a += gc_s[n][k];
+                    pa = reinterpret_cast<const float4*>(gc_t[tid - R_BC]);
                 } else {
-                    const int k = tid / NPF, i = tid % NPF;
-                    _Pragma("unroll 8") for (int n = 0; n < NPN; ++n) a = fmaf(gc_s[n][k], x_s[n][i], a);
+                    pa = reinterpret_cast<const float4*>(gc_t[tid / NPF]);
+                    pb = reinterpret_cast<const float4*>(x_t[tid % NPF]);
+                }
+                float a = 0.f;
+                if (pb) {
+#pragma unroll
+                    for (int m4 = 0; m4 < NPN / 4; ++m4) {
+                        const float4 u = pa[m4], v = pb[m4];
+                        a = fmaf(u.x, v.x, a); a = fmaf(u.y, v.y, a); a = fmaf(u.z, v.z, a); a = fmaf(u.w, v.w, a);
+                    }
+                } else {
+#pragma unroll
+                    for (int m4 = 0; m4 < NPN / 4; ++m4) { const float4 u = pa[m4]; a += u.x; a += u.y; a += u.z; a += u.w; }
                 }
                 wacc += a;
             }
@@ -153,13 +169,13 @@ __global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __re
                 const int o = tid / W, j = tid % W;
                 float a = 0.f;
 #pragma unroll
-                for (int dg = 0; dg < NDEG; ++dg) a += god_s[o * NDEG + dg][j];
+                for (int dg = 0; dg < NDEG; ++dg) a += god_t[j][o * NDEG + dg];
                 odacc += a;
             } else if (tid < (NOCT + NDEG) * W) {
                 const int dg = (tid - NOCT * W) / W, j = tid % W;
                 float a = 0.f;
 #pragma unroll
-                for (int o = 0; o < NOCT; ++o) a += god_s[o * NDEG + dg][j];
+                for (int o = 0; o < NOCT; ++o) a += god_t[j][o * NDEG + dg];
                 odacc += a;
             }
         }
