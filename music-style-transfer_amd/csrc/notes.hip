@@ -411,8 +411,8 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
 // ============================================================================ row-wise tiny Linear
 // One lane per row: the K_in inputs and N_out outputs of a row live in registers, the weights are
 // LDS-broadcast, rows are read / written with the widest aligned vector the widths allow.  Backward
-// does input gradient and weight gradient in one pass: every lane stages its row's dZ and x in LDS,
-// then "role" lanes (one per weight / bias element) sum the 256 staged rows in row order and keep
+// does input gradient and weight gradient in one pass: every lane stages its row's dZ and x in LDS
+// (transposed, [feature][row]), then "role" lanes (one per weight / bias element) sum the 256 staged rows in row order and keep
 // their element in a register across the grid-stride loop — one slab row per workgroup, no shuffles,
 // no float atomics.
 __device__ __forceinline__ float rl_act(int act, float z, int col) {
@@ -480,10 +480,11 @@ template <int KIN, int NOUT>
 __global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __restrict__ dp, Bases b) {
     const RowLinDesc d = dp[blockIdx.y];
     constexpr int NACC = NOUT * KIN + NOUT;            // weight (NOUT x KIN) then bias (NOUT), the parameters' own order
-    constexpr int RW = (NOUT + KIN) | 1;               // staged row: dZ[NOUT] | x[KIN], odd stride => conflict-free row writes
+    constexpr int RW = NOUT + KIN;                     // staged per row: dZ[NOUT] | x[KIN]
+    constexpr int RP = 256 + 4;                        // transposed staging [feature][row]: lane-contiguous writes, 16-byte role reads
     static_assert(NACC <= 256, "role count exceeds the workgroup");
     __shared__ float w_s[NOUT * KIN];
-    __shared__ float st[256][RW];
+    __shared__ __attribute__((aligned(16))) float st[RW][RP];
     const int tid = threadIdx.x;
     for (int i = tid; i < NOUT * KIN; i += 256) w_s[i] = b.p[SP_PAR][d.w_off + i];
     const float* x0 = b.p[SP_WS] + d.x_off;
@@ -504,9 +505,9 @@ __global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __res
             rl_load<NOUT>(y0 + (int64_t)row * NOUT, y);
             rl_load<NOUT>(gy0 + (int64_t)row * NOUT, g);
 #pragma unroll
-            for (int n = 0; n < NOUT; ++n) { g[n] *= rl_dact(d.act, y[n], n); st[tid][n] = g[n]; }
+            for (int n = 0; n < NOUT; ++n) { g[n] *= rl_dact(d.act, y[n], n); st[n][tid] = g[n]; }
 #pragma unroll
-            for (int k = 0; k < KIN; ++k) st[tid][NOUT + k] = x[k];
+            for (int k = 0; k < KIN; ++k) st[NOUT + k][tid] = x[k];
             if (d.xgrad) {
                 float dx[KIN];
                 rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
@@ -521,17 +522,22 @@ __global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __res
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < NOUT + KIN; ++j) st[tid][j] = 0.f;
+            for (int j = 0; j < NOUT + KIN; ++j) st[j][tid] = 0.f;
         }
         __syncthreads();
         if (tid < NACC) {
             float a = 0.f;
+            const float4* pa = reinterpret_cast<const float4*>(st[rn]);
             if (rk >= 0) {
-#pragma unroll 8
-                for (int r = 0; r < 256; ++r) a = fmaf(st[r][rn], st[r][rk], a);
+                const float4* pb = reinterpret_cast<const float4*>(st[rk]);
+#pragma unroll 4
+                for (int r4 = 0; r4 < 64; ++r4) {
+                    const float4 u = pa[r4], v = pb[r4];
+                    a = fmaf(u.x, v.x, a); a = fmaf(u.y, v.y, a); a = fmaf(u.z, v.z, a); a = fmaf(u.w, v.w, a);
+                }
             } else {
-#pragma unroll 8
-                for (int r = 0; r < 256; ++r) a += st[r][rn];
+#pragma unroll 4
+                for (int r4 = 0; r4 < 64; ++r4) { const float4 u = pa[r4]; a += u.x; a += u.y; a += u.z; a += u.w; }
             }
             wacc += a;
         }
