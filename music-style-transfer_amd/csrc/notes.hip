@@ -201,6 +201,17 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
     float* ws = b.p[SP_WS];
     const int QF = d.Q * NF;
     const int n = tid, o = n / NDEG, dg = n - o * NDEG;
+    // the octave | degree rows of the NEXT (qf, c) sit in 8 registers per lane while the current one is processed
+    constexpr int NLO = NOCT * PSA_HW, NOD = (NOCT + NDEG) * PSA_HW, NPRE = (NOD + 63) / 64;
+    float od[NPRE];
+    auto fetch_od = [&](int64_t row) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int i = tid + 64 * q;
+            od[q] = i < NLO ? ws[d.oct_off + row * NLO + i] : (i < NOD ? ws[d.deg_off + row * (NOD - NLO) + (i - NLO)] : 0.f);
+        }
+    };
+    if ((int)blockIdx.x < QF) fetch_od((int64_t)blockIdx.x);
     for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
         __syncthreads();
         float zm[NPF];
@@ -219,9 +230,14 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
         for (int c = 0; c < d.C; ++c) {
             const int64_t row = (int64_t)c * QF + qf;
             __syncthreads();
-            for (int i = tid; i < NOCT * PSA_HW; i += 64) lo_s[i] = ws[d.oct_off + row * (NOCT * PSA_HW) + i];
-            for (int i = tid; i < NDEG * PSA_HW; i += 64) ld_s[i] = ws[d.deg_off + row * (NDEG * PSA_HW) + i];
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int i = tid + 64 * q;
+                if (i < NLO) lo_s[i] = od[q]; else if (i < NOD) ld_s[i - NLO] = od[q];
+            }
             __syncthreads();
+            if (c + 1 < d.C) fetch_od((int64_t)(c + 1) * QF + qf);
+            else if (qf + (int)gridDim.x < QF) fetch_od((int64_t)(qf + gridDim.x));
             if (n < NPN) {
                 float z[NPF];
 #pragma unroll
