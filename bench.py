@@ -129,7 +129,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from style import _native as nat
     native = nat.get()                     # raises if libmst_amd.so is missing: no fallback
     B = max(1, args.clips_per_gpu)

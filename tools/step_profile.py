@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from bench import CLIP, WIDTHS, KIND_NAMES, init_params
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from style import _native as nat
 
 shape = dict(CLIP)
