@@ -269,7 +269,7 @@ def main():
             kind, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
             achieved = fl / (ms * 1e-3) / 1e12
             names = dict(KIND_NAMES)
-            if os.environ.get('MST_GEMM', 'mfma' if K >= 6 else 'valu') == 'mfma':
+            if plan.gemm_tile == 64:
                 names[0] = 'gemm_mfma_kernel'            # plans with >= 6 clips per launch use the 64x64-tile GEMM
             for r in table_rows:
                 if r['kernel'] == 'gemm_kernel':

@@ -65,8 +65,22 @@ int64_t mst_param_floats(const mst_dims* d);
 int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int32_t name_cap,
                        int64_t* offset, int32_t* ndim, int32_t shape[3]);
 
+/* MST_OK when the HIP kernels are instantiated for the layer widths in `d` (the note-level kernels exist for
+ * melody_size 8 and 4 with the reference's derived widths), MST_ERR_UNSUPPORTED otherwise: lets the Python
+ * constructors fail early instead of at the first forward. */
+int32_t mst_widths_supported(const mst_dims* d);
+
 /* ---- plan: static launch schedule + device-side descriptors for one mst_dims. */
-mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);
+typedef struct {
+    int32_t gemm_tile;          /* 0 = choose from the clip count (64x64 tiles from 6 clips per launch on, else 32x32
+                                 * split-K tiles); 32 / 64 = force that tiling (experiments, parity tests) */
+    int32_t no_merge;           /* 1 = one launch per scheduled member (profiling aid); 0 = merge a dependency level's
+                                 * launches of one kernel */
+    int32_t reserved[6];        /* must be 0 */
+} mst_plan_options;
+mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
+mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);
+int32_t mst_plan_gemm_tile(const mst_plan* p);                                       /* 32 or 64 */
 void mst_plan_destroy(mst_plan* p);
 int64_t mst_plan_workspace_floats(const mst_plan* p);
 /* Named tensor inside the workspace: activation offset, gradient offset, element count.

@@ -3,15 +3,18 @@
 // Every dense contraction of the model goes through this kernel: the broadcast-concat
 // Linears (cat_with_broadcast + nn.Linear, style/utils/pytorch.py:54-65), the note-axis
 // Conv1d as an implicit-im2col GEMM (style/model.py:46-53,82), the LSTM input projections,
-// and all their weight/input gradients.  Operands are *accessors*: the concatenated,
-// broadcast input row is never materialised in HBM — each LDS tile is gathered straight from
-// the source tensors — and bias/activation (or the activation derivative on the backward
-// side) are fused into the tile load / epilogue.
+// and all their weight/input gradients.  Operands are *accessors* (dense, activation-gradient,
+// im2col, permuted weight, conv-gradient): the conv's im2col matrix and the transposed /
+// permuted weight views are never materialised, and bias/activation (or the activation derivative
+// on the backward side) are fused into the tile load / epilogue.  The broadcast-concat input of a
+// Linear IS materialised once per consumer group by gather_kernel below (its backward is
+// segred_kernel), so those GEMMs read one dense operand.
 //
-// Tiling: 32x32 outputs x KD-deep k-tile (KD = 32 / 64 / 128 by the descriptor's k range) per
+// Latency flavour (gemm_kernel): 32x32 outputs x KD-deep k-tile (KD = 32 / 64 / 128 by the descriptor's k range) per
 // 1024-thread workgroup; the sixteen waves split the k-tile (in-block split-K), each running its k rows through
-// v_mfma_f32_32x32x2_f32 (one 32x32 accumulator tile per wave), LDS tiles stored k-major (+4 pad).  The model's GEMMs are small (tens of MFLOP) and latency-bound, so the
-// tile is chosen for workgroup count and a short dependent k chain, not for peak FLOP/s.  blockIdx.y selects the
+// v_mfma_f32_32x32x2_f32 (one 32x32 accumulator tile per wave), LDS tiles stored k-major (+1 pad).  One clip's GEMMs are
+// small (tens of MFLOP) and latency-bound, so the tile is chosen for workgroup count and a short dependent k chain.
+// Throughput flavour (gemm_mfma_kernel, plans with >= 6 clips per launch): further down.
 // Independent GEMMs share one launch: the 1-D grid is the concatenation of every member's
 // (tile, k-split) workgroups; k-splits of weight gradients write deterministic slabs that are
 // reduced later in order.

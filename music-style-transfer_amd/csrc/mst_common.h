@@ -43,7 +43,7 @@ struct Bases { float* p[SP_COUNT]; };
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SIGOUT = 2, ACT_BPM = 3 };
 
 // ---- generic GEMM: C[m,n] = epilogue(sum_k A(m,k) * B(k,n))
-enum { OPK_DENSE = 0, OPK_CAT = 1, OPK_ACTGRAD = 2, OPK_IM2COL = 3, OPK_PERMW = 4, OPK_CONVGRAD = 5 };
+enum { OPK_DENSE = 0, OPK_ACTGRAD = 2, OPK_IM2COL = 3, OPK_PERMW = 4, OPK_CONVGRAD = 5 };
 #define MAX_SEG 6
 struct Seg {
     int32_t space, ld, start, width;

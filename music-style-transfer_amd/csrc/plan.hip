@@ -192,12 +192,7 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
 enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B };
-struct Step {
-    int kind, first, count, a, b, stage;
-    int lane = 0;                 // dataflow lane (0 = the caller's stream)
-    std::vector<int> waits;       // steps of other lanes whose completion event this step waits for
-    bool record = false;          // some later step on another lane (or the final join) waits for this one
-};
+struct Step { int kind, first, count, a, b, stage; };
 struct Acc { int space; int64_t lo, hi; bool w; };
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
@@ -225,11 +220,8 @@ struct mst_plan {
     std::vector<SlabBlock> slab_blocks[3]; SlabBlock* d_slab_blocks[3] = {nullptr, nullptr, nullptr};
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     int err = 0;
-    int nlanes = 1;
+    mst_plan_options opt{};       // as given to mst_plan_create_ex (zeros = defaults)
     int mfma = 0;                 // GEMM tiling of this plan: 1 = 64x64 tiles (batched, FLOP-bound plans), 0 = 32x32 split-K tiles (latency)
-    struct LaneCtx { std::vector<hipStream_t> side; std::vector<hipEvent_t> ev; hipEvent_t start = nullptr; };
-    mutable std::map<std::pair<hipStream_t, int>, LaneCtx> lane_ctx;   // per (caller stream, pass): side streams + step events
-                                                                        // (an event is recorded once per capture)
 
     int P() const { return d.C * d.R * d.T; }
     int Q() const { return d.R * d.T; }
@@ -892,8 +884,6 @@ static bool conflicts(const std::vector<Acc>& a, const std::vector<Acc>& b) {
     return false;
 }
 
-static void assign_lanes(const mst_plan& pl, std::vector<Step>& steps, const std::vector<std::vector<Acc>>& acc, int nlanes);
-
 void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out, bool across_stages) {
     const int n = (int)seq.size();
     std::vector<std::vector<Acc>> acc(n);
@@ -906,16 +896,13 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
         if (level[i] > maxlevel) maxlevel = level[i];
     }
     std::vector<char> done(n, 0);
-    std::vector<std::vector<Acc>> macc;        // accesses of the merged steps, in `out` order
     for (int lv = 0; lv <= maxlevel; ++lv) {
         for (int i = 0; i < n; ++i) {
             if (done[i] || level[i] != lv) continue;
             const Step& s0 = seq[i];
-            static const bool no_merge = getenv("MST_NO_MERGE") != nullptr;      // profiling aid: one launch per member
-            const bool mergeable = !no_merge && (s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
+            const bool mergeable = !opt.no_merge && (s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
                                    s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
             Step m = s0; m.count = 0;
-            std::vector<Acc> mac;
             const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
             const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B;
             const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B;
@@ -935,7 +922,6 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 if (is_lstm && ((s.b > 64) != (s0.b > 64))) continue;
                 if (j != i && !mergeable) continue;
                 done[j] = 1;
-                mac.insert(mac.end(), acc[j].begin(), acc[j].end());
                 for (int q = 0; q < s.count; ++q) members.push_back(s.first + q);
                 m.stage |= s.stage;
                 if (s.a > m.a) m.a = s.a;
@@ -984,57 +970,16 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 m.a = total;
             }
             out.push_back(m);
-            macc.push_back(std::move(mac));
         }
     }
-    assign_lanes(*this, out, macc, nlanes);
-}
-
-// Dataflow lanes: exact dependencies between the merged launches (transitively reduced), then a greedy
-// assignment to a few streams — a launch continues the lane of a predecessor that is that lane's tail, else it
-// takes the lane whose tail is already one of its ancestors (no false dependency), else the least recently
-// used lane.  Under hipGraph capture the event edges become graph edges: independent branches of the model
-// (rhythm / melody / style encoders, song-info vs applier, weight-gradient GEMMs) overlap for free.
-static void assign_lanes(const mst_plan& pl, std::vector<Step>& steps, const std::vector<std::vector<Acc>>& acc, int nlanes) {
-    const int n = (int)steps.size();
-    std::vector<std::vector<char>> anc(n, std::vector<char>(n, 0));
-    std::vector<std::vector<int>> preds(n);
-    for (int i = 0; i < n; ++i) {
-        for (int j = i - 1; j >= 0; --j) {
-            if (anc[i][j]) continue;
-            if (!conflicts(acc[i], acc[j])) continue;
-            preds[i].push_back(j);
-            anc[i][j] = 1;
-            for (int k = 0; k < j; ++k) if (anc[j][k]) anc[i][k] = 1;
-        }
-    }
-    std::vector<int> tail(nlanes, -1), last_use(nlanes, -1);
-    for (int i = 0; i < n; ++i) {
-        int lane = -1;
-        for (int p : preds[i]) if (tail[steps[p].lane] == p) { lane = steps[p].lane; break; }   // preds are in descending order
-        if (lane < 0) for (int l = 0; l < nlanes && lane < 0; ++l) if (tail[l] < 0 || anc[i][tail[l]]) lane = l;
-        if (lane < 0) { lane = 0; for (int l = 1; l < nlanes; ++l) if (last_use[l] < last_use[lane]) lane = l; }
-        steps[i].lane = lane;
-        for (int p : preds[i]) if (steps[p].lane != lane) { steps[i].waits.push_back(p); steps[p].record = true; }
-        tail[lane] = i; last_use[lane] = i;
-    }
-    for (int l = 1; l < nlanes; ++l) if (tail[l] >= 0) steps[tail[l]].record = true;            // joined at the end of the pass
-    (void)pl;
 }
 
 void mst_plan::schedule() {
-    const char* env = getenv("MST_LANES");
-    // experimental, default off: on ROCm 7.2 the cross-stream graph edges cost more than the overlap returns
-    // (815 -> 870 it/s with 2 lanes, 741 with 4; nested inside another capture fork hipStreamEndCapture crashes)
-    nlanes = env ? atoi(env) : 1;
     // Two GEMM tilings, both on v_mfma_f32_32x32x2_f32: few clips per launch are latency-bound and want many small
     // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about six clips per launch on
     // the launches fill the chip and the 64x64-tile kernel (16-byte tile loads) wins (measured crossover between 4 and 8
-    // clips: 2475 vs 2306 clip-it/s at 4, 3060 vs 3340 at 8).  MST_GEMM=mfma|valu forces the 64x64 / 32x32 tiling (experiments, tests).
-    const char* ge = getenv("MST_GEMM");
-    mfma = ge ? (strcmp(ge, "mfma") == 0) : (K() >= 6);
-    if (nlanes < 1) nlanes = 1;
-    if (nlanes > 8) nlanes = 8;
+    // clips: 2475 vs 2306 clip-it/s at 4, 3060 vs 3340 at 8).  mst_plan_options.gemm_tile = 32 | 64 forces one (experiments, tests).
+    mfma = opt.gemm_tile == 64 ? 1 : (opt.gemm_tile == 32 ? 0 : (K() >= 6));
     std::vector<Step> fwd, bwd;
     for (auto& op : ops) for (auto s : op.fwd) { s.stage = op.stage; fwd.push_back(s); }
     for (size_t i = ops.size(); i-- > 0;) for (auto s : ops[i].bwd) { s.stage = ops[i].stage; bwd.push_back(s); }
@@ -1070,10 +1015,22 @@ int mst_plan::upload() {
     return e ? MST_ERR_ALLOC : MST_OK;
 }
 
-extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) {
+extern "C" int32_t mst_widths_supported(const mst_dims* d) {
+    if (!dims_ok(d)) return MST_ERR_ARG;
+    const Sizes z = mst_sizes(*d);
+    if (!notes_widths_supported(z.MEL, z.ME_CW, z.PSA_ML)) return MST_ERR_UNSUPPORTED;
+    if (z.H > 256 || z.SE_L > 256 || z.HB > 256) return MST_ERR_UNSUPPORTED;
+    return MST_OK;
+}
+
+extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) { return mst_plan_create_ex(d, nullptr, status); }
+
+extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status) {
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && (opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64)) { *status = MST_ERR_ARG; return nullptr; }
     mst_plan* p = new mst_plan();
+    if (opt) p->opt = *opt;
     p->d = *d; p->z = mst_sizes(*d);
     if (p->d.clips < 1) p->d.clips = 1;
     build_params(*d, p->z, p->pt);
@@ -1091,15 +1048,12 @@ extern "C" void mst_plan_destroy(mst_plan* p) {
     hipFree(p->d_gemm_starts); hipFree(p->d_rowlins);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
-    for (auto& kv : p->lane_ctx) {
-        for (auto s : kv.second.side) hipStreamDestroy(s);
-        for (auto e : kv.second.ev) hipEventDestroy(e);
-        if (kv.second.start) hipEventDestroy(kv.second.start);
-    }
     delete p;
 }
 
 extern "C" int64_t mst_plan_workspace_floats(const mst_plan* p) { return p ? (int64_t)p->K() * (2 * p->act_top + p->tmp_top) : MST_ERR_ARG; }
+
+extern "C" int32_t mst_plan_gemm_tile(const mst_plan* p) { return p ? (p->mfma ? 64 : 32) : MST_ERR_ARG; }
 
 extern "C" int32_t mst_plan_layout(const mst_plan* p, int64_t out[4]) {
     if (!p || !out) return MST_ERR_ARG;
@@ -1157,46 +1111,13 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     return MST_ERR_ARG;
 }
 
-// Run one pass (a scheduled list filtered by stage) over the dataflow lanes: lane 0 is the caller's stream.
-static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, int pass, const Bases& b, hipStream_t main) {
-    if (p->nlanes <= 1 || mask != MST_STAGE_ALL) {      // lanes are computed for the full list only
-        for (auto& s : list) {
-            if (!(s.stage & mask)) continue;
-            int e = run_step(p, s, b, main);
-            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
-        }
-        return MST_OK;
-    }
-    mst_plan::LaneCtx& cx = p->lane_ctx[std::make_pair(main, pass)];
-    static const int dbg_flags = getenv("MST_LANE_FLAGS") ? atoi(getenv("MST_LANE_FLAGS")) : 0;
-    const unsigned sflag = (dbg_flags & 1) ? 0u : (unsigned)hipStreamNonBlocking;
-    const unsigned eflag = (dbg_flags & 2) ? 0u : (unsigned)hipEventDisableTiming;
-    if (cx.side.empty()) {
-        cx.side.resize(p->nlanes - 1);
-        for (auto& s : cx.side) if (hipStreamCreateWithFlags(&s, sflag) != hipSuccess) return MST_ERR_ALLOC;
-        if (hipEventCreateWithFlags(&cx.start, eflag) != hipSuccess) return MST_ERR_ALLOC;
-    }
-    if (cx.ev.size() < list.size()) {
-        const size_t old_n = cx.ev.size();
-        cx.ev.resize(list.size());
-        for (size_t i = old_n; i < cx.ev.size(); ++i) if (hipEventCreateWithFlags(&cx.ev[i], eflag) != hipSuccess) return MST_ERR_ALLOC;
-    }
-    auto stream_of = [&](int lane) { return lane == 0 ? main : cx.side[lane - 1]; };
-    std::vector<char> started(p->nlanes, 0);
-    hipEventRecord(cx.start, main);
-    for (size_t i = 0; i < list.size(); ++i) {
-        const Step& s = list[i];
-        hipStream_t st = stream_of(s.lane);
-        if (s.lane != 0 && !started[s.lane]) { hipStreamWaitEvent(st, cx.start, 0); started[s.lane] = 1; }
-        for (int w : s.waits) hipStreamWaitEvent(st, cx.ev[w], 0);
-        int e = run_step(p, s, b, st);
+// Run one pass (a scheduled list filtered by stage) on the caller's stream.
+static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b, hipStream_t main) {
+    for (auto& s : list) {
+        if (!(s.stage & mask)) continue;
+        int e = run_step(p, s, b, main);
         if (e) return e < 0 ? e : MST_ERR_LAUNCH;
-        if (s.record) hipEventRecord(cx.ev[i], st);
     }
-    // join: everything enqueued after this call on the caller's stream sees the whole pass
-    std::vector<int> tail(p->nlanes, -1);
-    for (size_t i = 0; i < list.size(); ++i) tail[list[i].lane] = (int)i;
-    for (int l = 1; l < p->nlanes; ++l) if (tail[l] >= 0) hipStreamWaitEvent(main, cx.ev[tail[l]], 0);
     return MST_OK;
 }
 
@@ -1205,7 +1126,7 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
     if (!p || !params || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, nullptr, ws, pitched, unpitched);
-    return run_pass(p, p->list(mask, 0), mask, 0, b, (hipStream_t)stream);
+    return run_pass(p, p->list(mask, 0), mask, b, (hipStream_t)stream);
 }
 
 extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
@@ -1240,7 +1161,7 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
     {
-        int e = run_pass(p, p->list(mask, 1), mask, 1, b, (hipStream_t)stream);
+        int e = run_pass(p, p->list(mask, 1), mask, b, (hipStream_t)stream);
         if (e) return e;
     }
     for (int s = 2; s >= 0; --s) {

@@ -38,13 +38,29 @@ class Dims(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class PlanOptions(C.Structure):
+    _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('reserved', C.c_int32 * 6)]
+
+
+def options_from_env():
+    """Developer switches of the Python binding; the C library itself reads no environment.
+    MST_GEMM=mfma|valu forces the 64x64 / 32x32 GEMM tiling, MST_NO_MERGE=1 gives one launch per scheduled member."""
+    ge = os.environ.get('MST_GEMM')
+    if ge not in (None, '', 'mfma', 'valu'):
+        raise MstError(f'MST_GEMM={ge!r}: expected mfma or valu')
+    return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))))
+
+
 _P = C.c_void_p
 _SIGS = {
     'mst_param_count': (C.c_int32, [C.POINTER(Dims)]),
     'mst_param_floats': (C.c_int64, [C.POINTER(Dims)]),
     'mst_param_info': (C.c_int32, [C.POINTER(Dims), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32 * 3)]),
+    'mst_widths_supported': (C.c_int32, [C.POINTER(Dims)]),
     'mst_plan_create': (_P, [C.POINTER(Dims), C.POINTER(C.c_int32)]),
+    'mst_plan_create_ex': (_P, [C.POINTER(Dims), C.POINTER(PlanOptions), C.POINTER(C.c_int32)]),
+    'mst_plan_gemm_tile': (C.c_int32, [_P]),
     'mst_plan_destroy': (None, [_P]),
     'mst_plan_workspace_floats': (C.c_int64, [_P]),
     'mst_plan_tensor': (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -120,11 +136,12 @@ class Native:
         return self.lib.mst_param_floats(C.byref(dims))
 
     def plan(self, dims, device):
-        key = (dims.key(), str(device))
+        opts = options_from_env()
+        key = (dims.key(), str(device), tuple(sorted(opts.items())))
         if key in self._plans:
             self._plans.move_to_end(key)
             return self._plans[key]
-        plan = self._plans[key] = Plan(self, dims, device)
+        plan = self._plans[key] = Plan(self, dims, device, **opts)
         while len(self._plans) > max(1, self._plan_cap):
             self._plans.popitem(last=False)       # the Plan (and its workspace) dies when its last autograd user lets go
         return plan
@@ -138,15 +155,21 @@ def current_stream(device):
 
 class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
+    WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
+        env = options_from_env()
+        opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
+                           no_merge=env['no_merge'] if no_merge is None else int(no_merge))
         st = C.c_int32()
-        self.handle = self.lib.mst_plan_create(C.byref(dims), C.byref(st))
+        self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:
-            check(st.value or -1, 'mst_plan_create')
+            check(st.value or -1, 'mst_plan_create_ex')
+        self.gemm_tile = self.lib.mst_plan_gemm_tile(self.handle)
         n = self.lib.mst_plan_workspace_floats(self.handle)
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._free_ws = []
         self._slots = {}
         lay = (C.c_int64 * 4)()
         check(self.lib.mst_plan_layout(self.handle, C.byref(lay)), 'mst_plan_layout')
@@ -169,8 +192,18 @@ class Plan:
         return self._slots[name]
 
     def new_ws(self):
-        """A fresh workspace for this plan (one per in-flight forward whose backward is still pending)."""
+        """A fresh workspace for this plan."""
         return torch.zeros_like(self.ws)
+
+    def acquire_ws(self):
+        """A workspace for one grad-enabled forward whose backward is pending: taken from the plan's pool (nothing is
+        zero-filled on reuse: every slot is written before it is read), allocated only when the pool is empty.  The pool
+        holds FREE workspaces only, so one whose backward never runs is simply garbage-collected."""
+        return self._free_ws.pop() if self._free_ws else self.new_ws()
+
+    def release_ws(self, ws):
+        if ws is not self.ws and len(self._free_ws) < self.WS_POOL_CAP:
+            self._free_ws.append(ws)
 
     def view(self, name, shape=None, ws=None, clip=0):
         off, _, n = self.slot(name)

@@ -191,6 +191,10 @@ class StyleTransferModel(nn.Module):
                 if widths.setdefault(k, v) != v:
                     raise ValueError(f'sub-modules disagree on {k}_size: {widths[k]} vs {v}')
         self._widths = widths
+        # fail here, not at the first forward: the note-level HIP kernels exist for melody_size 8 and 4 only
+        if _native.get().lib.mst_widths_supported(_dims(**widths)) != 0:
+            raise _native.MstError(f'layer widths {widths} are outside the instantiated HIP kernels '
+                                   '(melody_size must be 8 or 4; LSTM hidden sizes <= 256)')
         self._flat = self._gflat = None
         self._offsets = None
 
@@ -241,19 +245,22 @@ class StyleTransferModel(nn.Module):
         return next(self.parameters())
 
     # ---- reference surface (style/model.py:751-793) ----------------------------------------
+    # Grad mode is read HERE: inside autograd.Function.forward it is always off, so the Functions take it as a plain bool.
     def extract_style(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
-        return _Extract.apply(self, self._anchor(), mode, bpm, pitched_channels, instruments_features, unpitched_channels)
+        return _Extract.apply(self, self._anchor(), torch.is_grad_enabled(), mode, bpm, pitched_channels, instruments_features,
+                              unpitched_channels)
 
     def predict_song_info(self, style, rhythm):
-        return _Predict.apply(self, self._anchor(), style, rhythm)
+        return _Predict.apply(self, self._anchor(), torch.is_grad_enabled(), style, rhythm)
 
     def apply_style(self, style, melody, rhythm, instruments_features, unpitched=False):
-        x_pitched, x_unpitched = _Apply.apply(self, self._anchor(), style, melody, rhythm, instruments_features, bool(unpitched))
+        x_pitched, x_unpitched = _Apply.apply(self, self._anchor(), torch.is_grad_enabled(), style, melody, rhythm,
+                                              instruments_features, bool(unpitched))
         return x_pitched, (x_unpitched if unpitched else None)
 
     def forward(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
-        ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), mode, bpm, pitched_channels, instruments_features,
-                                            unpitched_channels)
+        ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), torch.is_grad_enabled(), mode, bpm, pitched_channels,
+                                            instruments_features, unpitched_channels)
         return (ip, mp, bp), xp, (xu if unpitched_channels is not None else None)
 
 
@@ -274,22 +281,33 @@ def _seed(plan, ws, name, g):
 
 
 class _StageFn(torch.autograd.Function):
-    """Common plumbing: one workspace per forward whose backward is pending."""
+    """Common plumbing: one workspace per forward whose backward is pending (two grad-enabled forwards of the same
+    shape may both be waiting for their backward, e.g. the summed loss of two clips); it comes from the plan's pool
+    and goes back when that backward has run.  Without grad the plan's own scratch workspace is reused."""
 
     @staticmethod
-    def _ws(plan):
-        return plan.new_ws() if torch.is_grad_enabled() else plan.ws
+    def _ws(plan, grad):
+        return plan.acquire_ws() if grad else plan.ws
+
+    @staticmethod
+    def _take(ctx):
+        """The saved state of a forward, exactly once: its workspace goes back to the pool after this backward."""
+        stuff, ctx.stuff = ctx.stuff, None
+        if stuff is None:
+            raise _native.MstError('this stage was already back-propagated (its workspace has been recycled); '
+                                   'run the forward again instead of retain_graph=True')
+        return stuff
 
 
 class _Extract(_StageFn):
     @staticmethod
-    def forward(ctx, model, anchor, mode, bpm, pitched, instr, unpitched):
+    def forward(ctx, model, anchor, grad, mode, bpm, pitched, instr, unpitched):
         dev = anchor.device
         pitched = _f32c(pitched, dev)
         unpitched = None if unpitched is None else _f32c(unpitched, dev)
         _, C, R, T = pitched.shape[:4]
         plan = model._plan(C, R, T, unpitched is not None, dev)
-        ws = _StageFn._ws(plan)
+        ws = _StageFn._ws(plan, grad)
         plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instr, dev), ws=ws)
         plan.forward(_native.STAGE_EXTRACT, model._flat, pitched, unpitched, ws=ws)
         shp = _shapes(model, C, R, T)
@@ -298,22 +316,23 @@ class _Extract(_StageFn):
 
     @staticmethod
     def backward(ctx, g_style, g_melody, g_rhythm):
-        model, plan, ws, pitched, unpitched = ctx.stuff
+        model, plan, ws, pitched, unpitched = _StageFn._take(ctx)
         plan.zero_grads(_native.STAGE_EXTRACT, ws=ws)
         for k, g in (('style', g_style), ('melody', g_melody), ('rhythm', g_rhythm)):
             _seed(plan, ws, k, g)
         plan.backward(_native.STAGE_EXTRACT, model._flat, model._grad_target(), pitched, unpitched, ws=ws)
         model._publish_grads()
-        return (None,) * 7
+        plan.release_ws(ws)
+        return (None,) * 8
 
 
 class _Predict(_StageFn):
     @staticmethod
-    def forward(ctx, model, anchor, style, rhythm):
+    def forward(ctx, model, anchor, grad, style, rhythm):
         dev = anchor.device
         R, T = rhythm.shape[1:3]
         plan = model._plan(1, R, T, False, dev)
-        ws = _StageFn._ws(plan)
+        ws = _StageFn._ws(plan, grad)
         plan.view('style', ws=ws).copy_(_f32c(style, dev).reshape(-1))
         plan.view('rhythm', ws=ws).copy_(_f32c(rhythm, dev).reshape(-1))
         plan.forward(_native.STAGE_INFO, model._flat, None, None, ws=ws)
@@ -323,7 +342,7 @@ class _Predict(_StageFn):
 
     @staticmethod
     def backward(ctx, g_instr, g_mode, g_bpm):
-        model, plan, ws = ctx.stuff
+        model, plan, ws = _StageFn._take(ctx)
         plan.zero_grads(_native.STAGE_INFO, ws=ws)
         for k in ('style', 'rhythm'):
             plan.grad(k, ws=ws).zero_()
@@ -332,18 +351,20 @@ class _Predict(_StageFn):
         plan.backward(_native.STAGE_INFO, model._flat, model._grad_target(), None, None, ws=ws)
         model._publish_grads()
         shp = _shapes(model, 1, *[int(v) for v in (plan.dims.R, plan.dims.T)])
-        return None, None, plan.grad('style', shp['style'], ws=ws).clone(), plan.grad('rhythm', shp['rhythm'], ws=ws).clone()
+        out = (None, None, None, plan.grad('style', shp['style'], ws=ws).clone(), plan.grad('rhythm', shp['rhythm'], ws=ws).clone())
+        plan.release_ws(ws)
+        return out
 
 
 class _Apply(_StageFn):
     @staticmethod
-    def forward(ctx, model, anchor, style, melody, rhythm, instr, unpitched):
+    def forward(ctx, model, anchor, grad, style, melody, rhythm, instr, unpitched):
         dev = anchor.device
         instr = _f32c(instr, dev)
         C = instr.shape[1]
         R, T = rhythm.shape[1:3]
         plan = model._plan(C, R, T, unpitched, dev)
-        ws = _StageFn._ws(plan)
+        ws = _StageFn._ws(plan, grad)
         plan.set_inputs(instr=instr, ws=ws)
         for k, t in (('style', style), ('melody', melody), ('rhythm', rhythm)):
             plan.view(k, ws=ws).copy_(_f32c(t, dev).reshape(-1))
@@ -356,7 +377,7 @@ class _Apply(_StageFn):
 
     @staticmethod
     def backward(ctx, g_xp, g_xu):
-        model, plan, ws, unpitched = ctx.stuff
+        model, plan, ws, unpitched = _StageFn._take(ctx)
         plan.zero_grads(_native.STAGE_APPLY, ws=ws)
         for k in ('style', 'melody', 'rhythm'):
             plan.grad(k, ws=ws).zero_()
@@ -366,21 +387,23 @@ class _Apply(_StageFn):
         plan.backward(_native.STAGE_APPLY, model._flat, model._grad_target(), None, None, ws=ws)
         model._publish_grads()
         shp = _shapes(model, plan.dims.C, plan.dims.R, plan.dims.T)
-        return (None, None) + tuple(plan.grad(k, shp[k], ws=ws).clone() for k in ('style', 'melody', 'rhythm')) + (None, None)
+        out = (None, None, None) + tuple(plan.grad(k, shp[k], ws=ws).clone() for k in ('style', 'melody', 'rhythm')) + (None, None)
+        plan.release_ws(ws)
+        return out
 
 
 class _Forward(_StageFn):
     """extract_style + predict_song_info + apply_style in one workspace (the training path)."""
 
     @staticmethod
-    def forward(ctx, model, anchor, mode, bpm, pitched, instr, unpitched):
+    def forward(ctx, model, anchor, grad, mode, bpm, pitched, instr, unpitched):
         dev = anchor.device
         pitched = _f32c(pitched, dev)
         unpitched = None if unpitched is None else _f32c(unpitched, dev)
         _, C, R, T = pitched.shape[:4]
         U = unpitched is not None
         plan = model._plan(C, R, T, U, dev)
-        ws = _StageFn._ws(plan)
+        ws = _StageFn._ws(plan, grad)
         plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instr, dev), ws=ws)
         plan.forward(_native.STAGE_ALL, model._flat, pitched, unpitched, ws=ws)
         shp = _shapes(model, C, R, T)
@@ -392,7 +415,7 @@ class _Forward(_StageFn):
 
     @staticmethod
     def backward(ctx, g_instr, g_mode, g_bpm, g_xp, g_xu):
-        model, plan, ws, pitched, unpitched = ctx.stuff
+        model, plan, ws, pitched, unpitched = _StageFn._take(ctx)
         plan.zero_grads(_native.STAGE_ALL, ws=ws)
         for k, g in (('instruments_pred', g_instr), ('mode_pred', g_mode), ('bpm_pred', g_bpm), ('pitched_pred', g_xp)):
             _seed(plan, ws, k, g)
@@ -400,7 +423,8 @@ class _Forward(_StageFn):
             _seed(plan, ws, 'unpitched_pred', g_xu)
         plan.backward(_native.STAGE_ALL, model._flat, model._grad_target(), pitched, unpitched, ws=ws)
         model._publish_grads()
-        return (None,) * 7
+        plan.release_ws(ws)
+        return (None,) * 8
 
 
 # ---- losses (style/model.py:847-997) --------------------------------------------------------

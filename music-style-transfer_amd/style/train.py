@@ -12,6 +12,7 @@ an iteration stay on the device as one packed tensor, and every `flush_every` it
 them back for the CSV rows, the progress bar and the NaN assertion (which therefore fires up to
 `flush_every - 1` iterations late).  The optimizer is the fused HIP Adam (style/optim.py).
 """
+import csv
 import math
 import os
 
@@ -25,7 +26,6 @@ from style.model import (device, get_total_loss, PitchedChannelsEncoder, Unpitch
                          UnpitchedRhythmEncoder, StyleEncoder, MelodyEncoder, SongInfoModel, PitchedStyleApplier,
                          UnpitchedStyleApplier, StyleTransferModel)
 from style.optim import FusedAdam
-from style.utils.data import save_to_csv
 from style.utils.misc import ProgressBar, assert_dir
 from style.utils.parallel import iter_parallel
 
@@ -92,8 +92,19 @@ class LossLog:
                     self.pbar.update_values(1, unpitched_loss=leaf['channels_loss_unpitched_total'],
                                             unpitched_notes_loss=leaf['channels_loss_unpitched_notes_loss'])
         if self.path:
-            save_to_csv(self.path, data=rows, fieldnames=CSV_FIELDS)
+            self._append_rows(rows)
         self.pending = []
+
+    def _append_rows(self, rows):
+        """One CSV row per iteration with the flattened loss leaves (train-model.py:148-149), fixed columns
+        CSV_FIELDS; the header goes in only when this call creates the file."""
+        assert_dir(self.path)
+        fresh = not os.path.exists(self.path) or os.path.getsize(self.path) == 0
+        with open(self.path, 'a', newline='', encoding='utf-8') as f:
+            out = csv.writer(f)
+            if fresh:
+                out.writerow(CSV_FIELDS)
+            out.writerows([row[k] for k in CSV_FIELDS] for row in rows)
 
 
 def train(model, inputs, n_iterations=5000, iter_size=2, training_info_path='training.csv', save_path='snapshots/',

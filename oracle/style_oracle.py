@@ -359,10 +359,10 @@ def total_loss(instr_pred, instr_target, bpm_pred, bpm_target, mode_pred, mode_t
 
 
 def hard_output(x):
-    """style/model.py:818-832, out-of-place restatement (the reference also zeroes the
-    velocity slice of its INPUT in place; callers that rely on that are covered by the
-    product test, not here)."""
-    vel = x[..., 1:2] * (x[..., 1:2] > .01).float()
+    """style/model.py:818-832.  Like the reference (:822, `velocity *= ...` on a view) it zeroes the
+    sub-threshold velocities of its INPUT in place; pinned by tests/golden/inference_small.npz."""
+    vel = x[..., 1:2]
+    vel *= (vel > .01).float()
     if x.shape[-1] > 2:
         acc = x[..., 2:]
         hard = ((acc == acc.max(-1, keepdim=True)[0]) & (acc > .1)).float()

@@ -168,8 +168,68 @@ def trajectory_case():
     print('traj totals', out['losses'][:, keys.index('total')])
 
 
+def inference_case():
+    """Forward-only behaviour of the reference (style/style_transfer.py:41-54,101-131; style/model.py:751-782,818-832):
+    extract_style on a composition A (with percussion) and on a style song B (pitched only, unpitched_channels=None),
+    predict_song_info / apply_style with B's style on A's melody and rhythm, hard_output of the predictions (with its
+    in-place velocity mutation), hard_output on a hand-made tensor with ties / threshold values — plus the SUM of the
+    two clips' gradients before the optimizer step (train-model.py:126 accumulates), which pins two pending forwards."""
+    C, R, T = 2, 3, 2
+    model = build(SMALL, seed=7)
+    out = dict(widths=np.array([SMALL[k] for k in ('beat', 'bar', 'nrf', 'style', 'melody', 'rhythm')]),
+               crt=np.array([C, R, T]), density=np.array(0.05))
+    z0 = np.load(os.path.join(HERE, 'small_unpitched.npz'))      # same seed-7 parameters: not stored twice
+    for n, p in model.named_parameters():
+        assert np.array_equal(z0['p0/' + n], p.detach().numpy()), n
+    a = synth_clip(0, C, R, T, True, density=0.05)
+    b = synth_clip(1, C, R, T, True, density=0.05)
+    model.zero_grad()
+    iteration(model, a)
+    iteration(model, b)
+    for n, p in model.named_parameters():
+        out['g01/' + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    with torch.no_grad():
+        style_a, melody_a, rhythm_a = model.extract_style(a['mode'], a['bpm'], a['pitched'], a['instruments_features'], a['unpitched'])
+        style_b, _, _ = model.extract_style(b['mode'], b['bpm'], b['pitched'], b['instruments_features'], None)
+        ip, mp, bp = model.predict_song_info(style_b, rhythm_a)
+        instr = b['instruments_features'][:, :1]            # one predicted instrument (style_transfer.py:124-127)
+        xp, xu = model.apply_style(style_b, melody_a, rhythm_a, instr, True)
+        xp1, xu1 = model.apply_style(style_b, melody_a, rhythm_a, b['instruments_features'], False)
+        assert xu1 is None
+        out.update({'swap/style_a': style_a.numpy().copy(), 'swap/style_b': style_b.numpy().copy(),
+                    'swap/melody_a': melody_a.numpy().copy(), 'swap/rhythm_a': rhythm_a.numpy().copy(),
+                    'swap/instruments': ip.numpy().copy(), 'swap/mode': mp.numpy().copy(), 'swap/bpm': bp.numpy().copy(),
+                    'swap/pitched': xp.numpy().copy(), 'swap/unpitched': xu.numpy().copy(),
+                    'swap/pitched_all_channels': xp1.numpy().copy()})
+        hp = ref.hard_output(xp)                             # mutates xp's velocities in place (style/model.py:822)
+        hu = ref.hard_output(xu)
+        out.update({'swap/hard_pitched': hp.numpy().copy(), 'swap/hard_unpitched': hu.numpy().copy(),
+                    'swap/pitched_after': xp.numpy().copy(), 'swap/unpitched_after': xu.numpy().copy()})
+        # hand-made: velocities around the .01 threshold, accidental ties, maxima around the .1 threshold
+        g = torch.Generator().manual_seed(11)
+        x = torch.rand(1, 2, 1, 2, 10, 56, 5, generator=g)
+        x[..., 1] = torch.tensor([0., .005, .01, .0100001, .02, .5, 1., .009999])[torch.randint(0, 8, x.shape[:-1], generator=g)]
+        tie = torch.rand(x.shape[:-1], generator=g) < .3
+        x[..., 3] = torch.where(tie, x[..., 2], x[..., 3])                              # two equal maxima stay two ones
+        low = torch.rand(x.shape[:-1], generator=g) < .2
+        x[..., 2:] = torch.where(low.unsqueeze(-1), x[..., 2:] * .1, x[..., 2:])         # max <= .1 -> all zeros
+        x[0, 0, 0, 0, 0, 0, 2:] = torch.tensor([.1, .1, .05])
+        x[0, 0, 0, 0, 0, 1, 2:] = torch.tensor([.1000001, .05, .1000001])
+        u = torch.rand(1, 1, 1, 2, 10, 47, 2, generator=g)
+        u[..., 1] = torch.tensor([0., .005, .01, .0100001, .02, .5, 1., .009999])[torch.randint(0, 8, u.shape[:-1], generator=g)]
+        out['hard/x_in'] = x.numpy().copy(); out['hard/u_in'] = u.numpy().copy()
+        out['hard/x_out'] = ref.hard_output(x).numpy().copy(); out['hard/u_out'] = ref.hard_output(u).numpy().copy()
+        out['hard/x_after'] = x.numpy().copy(); out['hard/u_after'] = u.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'inference_small.npz'), **out)
+    print('inference: bpm', float(bp), 'hard ones', float(hp[..., 2:].sum()), len(out), 'arrays')
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['inference']:          # added later: leaves the earlier fixtures untouched
+        inference_case()
+        sys.exit(0)
     small_case('small_unpitched', True)
     small_case('small_pitched_only', False)
     full_case()
     trajectory_case()
+    inference_case()

@@ -139,25 +139,17 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
     return e, worst
 
 
-def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True):
+def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True, gemm_tile=None):
     """K different clips in ONE plan (mst_dims.clips = K) against (a) the oracle run clip by clip with
     gradients accumulating like train-model.py:126 and (b) the product's own one-clip plan run K times:
     per-clip activations and losses are bit-identical; the summed gradient is equal to rounding (the order in
     which per-clip partial sums meet differs)."""
     dims1 = make_dims(widths, C, R, T, unp)
     dimsK = make_dims(widths, C, R, T, unp, clips=K)
-    # a plan picks its GEMM tiling from the clip count (K >= 6: 64x64 tiles, else 32x32 split-K); the bitwise
-    # comparison needs both plans on the same one
-    old_flavour = os.environ.get('MST_GEMM')
-    os.environ['MST_GEMM'] = 'mfma' if K >= 4 else 'valu'
-    try:
-        planK = nat.Plan(native, dimsK, device)
-        plan1 = nat.Plan(native, dims1, device)
-    finally:
-        if old_flavour is None:
-            del os.environ['MST_GEMM']
-        else:
-            os.environ['MST_GEMM'] = old_flavour
+    # a plan picks its GEMM tiling from the clip count (K >= 6: 64x64 tiles, else 32x32 split-K) unless `gemm_tile` forces
+    # one; the bitwise comparison needs the one-clip plan on the tiling the batched plan chose
+    planK = nat.Plan(native, dimsK, device, gemm_tile=gemm_tile)
+    plan1 = nat.Plan(native, dims1, device, gemm_tile=planK.gemm_tile)
     flat, named, table = random_params(native, dims1, seed)
     clips = [synth_clip(10 + k, C, R, T, unp, density=density) for k in range(K)]
     params = flat.to(device)

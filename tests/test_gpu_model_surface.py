@@ -171,6 +171,76 @@ def test_trajectory_six_iterations_three_adam_steps():
         assert abs(float(x.abs().sum()) - ref[1]) < 2e-3 * ref[1] + 1e-6, n
 
 
+def test_two_pending_forwards_of_one_shape_keep_their_own_activations():
+    """Two grad-enabled forwards with the same (C, R, T) before either backward — the summed loss of two clips.
+    Each forward must own its workspace (a shared one lets the second overwrite the first's saved activations);
+    expected: the reference's g(clip 0) + g(clip 1) (tests/golden/inference_small.npz)."""
+    z, model = load_small('small_unpitched')
+    zi = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    clips = [to_dev(synth_clip(k, C, R, T, True, density=float(z['density']))) for k in (0, 1)]
+    _, l0 = reference_call(model, clips[0])
+    _, l1 = reference_call(model, clips[1])
+    assert abs(float(l0['total']) - float(z['loss0/total'])) < 2e-5 and abs(float(l1['total']) - float(z['loss1/total'])) < 2e-5
+    (l0['total'] + l1['total']).backward()
+    for n, p in model.named_parameters():
+        ref = zi['g01/' + n]
+        if np.linalg.norm(ref) > 1e-12:
+            assert rel(p.grad.cpu().numpy(), ref) < 5e-4, n
+    # the workspaces went back to the pool; a stage cannot be back-propagated twice
+    style, melody, rhythm = model.extract_style(clips[0]['mode'], clips[0]['bpm'], clips[0]['pitched'],
+                                                clips[0]['instruments_features'], clips[0]['unpitched'])
+    style.sum().backward(retain_graph=True)
+    from style import _native
+    with pytest.raises(_native.MstError):
+        style.sum().backward()
+
+
+def test_style_swap_inference_matches_reference_fixture():
+    """style/style_transfer.py:41-54,101-131 through the product surface: style of song B (pitched only,
+    unpitched_channels=None) on melody + rhythm of song A, then hard_output — against outputs of the reference."""
+    import style.model as m
+    z, model = load_small('small_unpitched')
+    zi = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    a, b = (to_dev(synth_clip(k, C, R, T, True, density=float(z['density']))) for k in (0, 1))
+    with torch.no_grad():
+        style_a, melody_a, rhythm_a = model.extract_style(a['mode'], a['bpm'], a['pitched'], a['instruments_features'], a['unpitched'])
+        style_b, _, _ = model.extract_style(b['mode'], b['bpm'], b['pitched'], b['instruments_features'], None)
+        ip, mp, bp = model.predict_song_info(style_b, rhythm_a)
+        xp, xu = model.apply_style(style_b, melody_a, rhythm_a, b['instruments_features'][:, :1], True)
+        xp_all, none = model.apply_style(style_b, melody_a, rhythm_a, b['instruments_features'], False)
+    assert none is None
+    for got, key in ((style_a, 'style_a'), (style_b, 'style_b'), (melody_a, 'melody_a'), (rhythm_a, 'rhythm_a'), (ip, 'instruments'),
+                     (mp, 'mode'), (bp, 'bpm'), (xp, 'pitched'), (xu, 'unpitched'), (xp_all, 'pitched_all_channels')):
+        assert tuple(got.shape) == zi['swap/' + key].shape, key
+        assert rel(got.cpu(), zi['swap/' + key]) < 1e-4, key
+    # hard_output on the REFERENCE's predictions (bit-exact decisions need bit-identical inputs)
+    for name in ('pitched', 'unpitched'):
+        x = torch.from_numpy(zi['swap/' + name]).to(DEV)
+        y = m.hard_output(x)
+        assert np.array_equal(y.cpu().numpy(), zi['swap/hard_' + name]), name
+        assert np.array_equal(x.cpu().numpy(), zi[f'swap/{name}_after']), name      # velocities zeroed in place
+
+
+def test_hard_output_matches_reference_fixture():
+    """style/model.py:818-832 on the hand-made tensor of inference_small.npz: velocities around .01, tied accidental
+    maxima (both stay 1), maxima at or below .1 (all zeros) — bit-exact, including the in-place mutation."""
+    import style.model as m
+    zi = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    for pre in ('hard/x', 'hard/u'):
+        x = torch.from_numpy(zi[pre + '_in']).to(DEV)
+        y = m.hard_output(x)
+        assert np.array_equal(y.cpu().numpy(), zi[pre + '_out']), pre
+        assert np.array_equal(x.cpu().numpy(), zi[pre + '_after']), pre
+
+
+def test_unsupported_widths_fail_in_the_constructor():
+    from style import _native
+    with pytest.raises(_native.MstError):
+        build_model(dict(FULL, melody=6))
+
+
 def test_hard_output_matches_oracle_and_mutates_input():
     import style.model as m
     x = torch.rand(1, 2, 2, 3, 10, 56, 5)

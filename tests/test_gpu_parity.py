@@ -46,25 +46,28 @@ def test_oracle_long_clip_config5_shape(native):
     print('long clip: all-gradient rel-L2', e, 'worst tensor', worst)
 
 
-def test_dataflow_lanes_opt_in_parity(native, monkeypatch):
-    # MST_LANES > 1 spreads independent launches over internal side streams with event edges (experimental)
-    monkeypatch.setenv('MST_LANES', '4')
-    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 3, True, check_bitwise=True)
-
-
 @pytest.mark.parametrize('C,R,T,unp,K', [(2, 2, 2, True, 3), (1, 3, 1, False, 2)])
 def test_batched_clips_small(native, C, R, T, unp, K):
     pc.batch_case(native, torch.device('cuda:0'), pc.SMALL, C, R, T, unp, K)
 
 
-def test_batched_clips_full_widths(native):
-    # BASELINE.json configs[2] in miniature: 5 different clips in one plan, every launch carrying all of them
-    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, 5)
+@pytest.mark.parametrize('K,tile', [(4, None), (5, None), (5, 64)])
+def test_batched_clips_full_widths(native, K, tile):
+    # BASELINE.json configs[2] in miniature: K different clips in one plan, every launch carrying all of them; K = 4, 5 run the
+    # product's default tiling for few clips per launch (32x32 split-K, batched), (5, 64) the 64x64 tiling
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, K, gemm_tile=tile)
 
 
-def test_batched_64_bench_clips_equal_sequential(native):
-    # BASELINE.json configs[2] at full size: 64 x (C=4, R=16, T=4) clips in one plan == 64 one-clip iterations, bit for bit
-    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, 64, check_oracle=False)
+def test_batched_32_bench_clips_configs3_per_gpu_share(native):
+    # BASELINE.json configs[3]: minibatch 256 over 8 GPUs = 32 x (C=4, R=16, T=4) clips per GPU in one plan; against the
+    # oracle clip by clip (outputs, 15 loss leaves per clip, summed gradient) and against 32 one-clip iterations bit for bit
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, 32)
+
+
+def test_batched_64_bench_clips_configs2(native):
+    # BASELINE.json configs[2] at full size: 64 x (C=4, R=16, T=4) clips in one plan == 64 one-clip iterations bit for bit,
+    # and == the oracle's 64 accumulated iterations (every clip's outputs and losses, the summed gradient)
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, 64)
 
 
 def test_single_clip_on_the_mfma_gemm(native, monkeypatch):

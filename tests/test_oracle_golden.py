@@ -81,6 +81,54 @@ def test_fast_lstm_matches_explicit():
     assert rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5
 
 
+def test_hard_output_against_reference_fixture():
+    """style/model.py:818-832 on a hand-made tensor (threshold velocities, accidental ties, maxima around .1) and on the
+    style-swap predictions, including the in-place mutation of the input's velocities — outputs of the reference itself."""
+    z = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    for pre in ('hard/x', 'hard/u'):
+        x = torch.from_numpy(z[pre + '_in']).clone()
+        y = so.hard_output(x)
+        assert np.array_equal(y.numpy(), z[pre + '_out']) and np.array_equal(x.numpy(), z[pre + '_after']), pre
+    for name in ('pitched', 'unpitched'):
+        x = torch.from_numpy(z['swap/' + name]).clone()
+        y = so.hard_output(x)
+        assert np.array_equal(y.numpy(), z['swap/hard_' + name]) and np.array_equal(x.numpy(), z[f'swap/{name}_after']), name
+
+
+def test_style_swap_inference_against_reference_fixture():
+    """style/style_transfer.py:41-54: style of song B (pitched only) applied to melody + rhythm of song A."""
+    z = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    _, flat = load_small('small_unpitched')          # the same seed-7 parameters (asserted by make_golden.py)
+    C, R, T = (int(v) for v in z['crt'])
+    a = synth_clip(0, C, R, T, True, density=float(z['density']))
+    b = synth_clip(1, C, R, T, True, density=float(z['density']))
+    with torch.no_grad():
+        style_a, melody_a, rhythm_a = so.extract_style(flat, a['mode'], a['bpm'], a['pitched'], a['instruments_features'], a['unpitched'])
+        style_b, _, _ = so.extract_style(flat, b['mode'], b['bpm'], b['pitched'], b['instruments_features'], None)
+        P = so.Params(flat)
+        ip, mp, bp = so.song_info(P.sub('song_info_model'), style_b, rhythm_a)
+        psa = P.sub('pitched_style_applier')
+        xp = so.pitched_style_applier(psa, style_b, melody_a, rhythm_a, b['instruments_features'][:, :1])
+        xu = so.unpitched_style_applier(P.sub('unpitched_style_applier'), style_b, rhythm_a)
+        xp_all = so.pitched_style_applier(psa, style_b, melody_a, rhythm_a, b['instruments_features'])
+    for got, key in ((style_a, 'style_a'), (style_b, 'style_b'), (melody_a, 'melody_a'), (rhythm_a, 'rhythm_a'), (ip, 'instruments'),
+                     (mp, 'mode'), (bp, 'bpm'), (xp, 'pitched'), (xu, 'unpitched'), (xp_all, 'pitched_all_channels')):
+        assert got.shape == z['swap/' + key].shape, key
+        assert rel(got, z['swap/' + key]) < TOL, key
+
+
+def test_two_clip_gradient_sum_against_reference_fixture():
+    z = np.load(os.path.join(GOLDEN, 'inference_small.npz'))
+    _, flat = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    for k in (0, 1):
+        so.iteration(flat, synth_clip(k, C, R, T, True, density=float(z['density'])))
+    for n, p in flat.items():
+        ref = z['g01/' + n]
+        if np.linalg.norm(ref) > 0:
+            assert rel(p.grad, ref) < 2e-4, n
+
+
 def test_hard_output():
     x = torch.rand(1, 2, 2, 2, 10, 56, 5)
     y = so.hard_output(x.clone())

@@ -43,7 +43,9 @@ def test_batched_clips_equal_sequential_iterations(C, R, T, unp, K):
 
 
 def test_batched_clips_on_the_mfma_gemm():
-    # batch_case forces the 64x64-tile GEMM for K >= 4 (the product switches at 6 clips per launch)
+    # the product switches to the 64x64-tile GEMM at 6 clips per launch; force it for a 4-clip plan, and run the
+    # default (32x32 tiles with 4 clips per launch) as well
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4, gemm_tile=64)
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4)
 
 

@@ -34,13 +34,16 @@ def test_progress_meter_matches_reference_formulas():
 
 
 def test_csv_log_and_prefetch(tmp_path):
-    from style.utils.data import save_to_csv
+    from style.train import LossLog, CSV_FIELDS
     from style.utils.parallel import iter_parallel
     path = str(tmp_path / 'log' / 'training.csv')
-    save_to_csv(path, iteration=0, total=1.5)
-    save_to_csv(path, data=[dict(iteration=1, total=2.5), dict(iteration=2, total='')], fieldnames=['iteration', 'total'])
+    log = LossLog(path, None, flush_every=100)
+    blank = {k: '' for k in CSV_FIELDS}
+    log._append_rows([dict(blank, iteration=0, total=1.5)])                       # creates the file: header + row
+    log._append_rows([dict(blank, iteration=1, total=2.5), dict(blank, iteration=2)])    # appends: no second header
     rows = list(csv.DictReader(open(path)))
     assert [r['iteration'] for r in rows] == ['0', '1', '2'] and rows[1]['total'] == '2.5' and rows[2]['total'] == ''
+    assert list(rows[0].keys()) == CSV_FIELDS
     assert list(iter_parallel(iter(range(7)))) == list(range(7))
 
     def failing():
