@@ -81,17 +81,123 @@ def cpu_baseline(flat, table, clip, seconds):
                        f'mkldnn LSTM), {dt:.1f} s')
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round NN that has one (profiles are committed per round)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{suffix}')))
+    return hits[-1] if hits else None
+
+
 def pmc_traffic(kernel, clips=1):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/), or None.
     bench.py cannot run the profiler on itself; the counters are collected by the command recorded in the file
     (one file per workload: one clip per launch, 64 clips per launch)."""
-    name = 'r01_pmc_hbm_traffic.json' if clips == 1 else f'r01_pmc_hbm_traffic_{clips}_clips.json'
-    path = os.path.join(ROOT, 'profiles', name)
+    path = _latest_profile('pmc_hbm_traffic.json' if clips == 1 else f'pmc_hbm_traffic_{clips}_clips.json')
     try:
         d = json.load(open(path))
         return d[kernel]['hbm_bytes_per_launch'] if kernel in d else None
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None
+
+
+def rocprof_avg_us(kernel, clips=1):
+    """Average duration (us) of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this bench
+    command (profiles/rNN_rocprofv3_kernel_stats[_K_clips].csv), or None."""
+    import csv
+    path = _latest_profile('rocprofv3_kernel_stats.csv' if clips == 1 else f'rocprofv3_kernel_stats_{clips}_clips.csv')
+    try:
+        for row in csv.DictReader(open(path)):
+            name = row.get('Name', '')
+            if name == kernel or name.startswith(kernel + '(') or name.startswith('void ' + kernel):
+                return float(row['AverageNs']) / 1e3
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+def roofline_leg(plan, nat, params, gparams, xp, xu, K, dt_per_clip_iter, breakdown=False):
+    """Every launch step of one pass timed with HIP events on the current stream (mst_plan_time_steps: 20 back-to-back
+    launches of the step on an otherwise idle GPU), aggregated per kernel; the roofline object is for the kernel with
+    the largest share.  achieved = sum of its descriptors' algorithmic FLOPs / sum of its launch durations."""
+    steps = plan.time_steps(nat.STAGE_ALL, False, params, gparams, xp, xu, reps=20) + \
+        plan.time_steps(nat.STAGE_ALL, True, params, gparams, xp, xu, reps=20)
+    agg = {}
+    for kind, ms, fl, by in steps:
+        a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+    total_ms = sum(a[1] for a in agg.values())
+    names = dict(KIND_NAMES)
+    if plan.gemm_tile == 64:
+        names[0] = 'gemm_mfma_kernel'            # plans with >= 6 clips per launch use the 64x64-tile GEMM
+    rows = [dict(kernel=names[kind], launches=cnt, total_us=round(ms * 1e3, 1), avg_us=round(ms * 1e3 / cnt, 2),
+                 share=round(ms / total_ms, 3), gflop=round(fl / 1e9, 4), mbytes=round(by / 1e6, 2))
+            for kind, (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+    kind, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = fl / (ms * 1e-3) / 1e12
+    prof_us = rocprof_avg_us(names[kind], K)
+    roof = dict(bound='mfma', kernel=names[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+                timer='HIP events (hipEventRecord on the launch stream) around 20 back-to-back launches of each step, GPU otherwise idle',
+                flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
+                frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(names[kind], K), clips_per_launch=K,
+                # the same kernel inside the committed rocprofv3 run of this command (there launches of the two concurrent
+                # accumulation iterations share the chip, so its average is longer than the isolated one)
+                rocprof_avg_launch_us=prof_us,
+                frac_from_rocprof=(fl / cnt / (prof_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if prof_us else None,
+                whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
+                                     achieved_tflops=algorithmic_flops_per_iter(**CLIP) / dt_per_clip_iter / 1e12))
+    if breakdown:
+        for r in rows:
+            print(json.dumps(r), file=sys.stderr)
+    return roof, rows
+
+
+def batched_leg(native, nat, dev, flat, K, passes, warm):
+    """BASELINE.json configs[2] beside the headline: K different clips in ONE batched plan (every launch carries all K),
+    Adam after every pass; one hipGraph replay = one pass + optimizer step.  Returns clip-iterations/s and the roofline
+    of the pass's dominant kernel."""
+    from tools.synth import synth_clip
+    dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1, clips=K)
+    plan = nat.Plan(native, dims, dev)
+    clips = [synth_clip(k, CLIP['C'], CLIP['R'], CLIP['T'], True) for k in range(K)]
+    for k, c in enumerate(clips):
+        plan.set_inputs(mode=c['mode'], bpm=c['bpm'], instr=c['instruments_features'], used=c['used_instruments'],
+                        bpm_target=float(c['bpm_int']), clip=k)
+    params = flat.to(dev)
+    g, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+    state = torch.zeros(4, device=dev)
+    xp = torch.cat([c['pitched'] for c in clips]).contiguous().to(dev)
+    xu = torch.cat([c['unpitched'] for c in clips]).contiguous().to(dev)
+    losses = torch.zeros(K, nat.N_LOSSES, device=dev)
+    P = nat.ptr
+    stream = torch.cuda.Stream(dev)
+
+    def one_pass():
+        plan.train_iteration(params, g, xp, xu, losses)
+        nat.check(native.lib.mst_adam_step(P(params), P(g), P(m), P(v), params.numel(), P(state), .01, .9, .999, 1e-8, 200, .9,
+                                           1, nat.current_stream(dev)), 'mst_adam_step')
+
+    with torch.cuda.stream(stream):
+        one_pass()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            one_pass()
+        for _ in range(warm):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        roof, rows = roofline_leg(plan, nat, params, g, xp, xu, K, dt / (passes * K))
+    return dict(value=passes * K / dt, unit='clip-iterations/s', ms_per_pass=dt / passes * 1e3, passes=passes, warmup_passes=warm,
+                config=dict(workload=f'{K} different 30 s clips (C=4,R=16,T=4 +percussion) on one GPU in one batched plan '
+                                     f'(BASELINE.json configs[2]): fwd+loss+bwd of all {K} clips per pass, gradients summed, '
+                                     'Adam+StepLR after every pass', clips_per_launch=K, iter_size=K, hip_graph=True,
+                            launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 3,
+                            final_total_loss_clip0=float(losses.cpu()[0, 0])),
+                roofline=roof, kernel_breakdown=rows)
 
 
 def main():
@@ -108,6 +214,10 @@ def main():
     ap.add_argument('--clips-per-gpu', type=int, default=1,
                     help='B > 1: B different clips per GPU in one batched plan (BASELINE.json configs[2]/[3]); a step is then one '
                          'clip-iteration, the optimizer steps once per pass over the B clips (iter_size = B per GPU)')
+    ap.add_argument('--batched-clips', type=int, default=64,
+                    help='with the default one-clip workload on 1 GPU: also time this many clips in one batched plan (configs[2]) for '
+                         'a few passes and report it as "batched" in the same JSON line; 0 = skip')
+    ap.add_argument('--batched-passes', type=int, default=12)
     ap.add_argument('--accum', choices=['streams', 'batched'], default='streams',
                     help='B = 1: run the iter_size = 2 accumulation iterations on two streams (default) or as one 2-clip batched pass')
     args = ap.parse_args()
@@ -255,34 +365,7 @@ def main():
         # ---- roofline leg: every launch step timed with HIP events on this stream (same workload)
         roof, table_rows = None, []
         if rank == 0:
-            steps = plan.time_steps(nat.STAGE_ALL, False, params, gparams, xp, xu, reps=20) + \
-                plan.time_steps(nat.STAGE_ALL, True, params, gparams, xp, xu, reps=20)
-            agg = {}
-            for kind, ms, fl, by in steps:
-                a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
-                a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
-            total_ms = sum(a[1] for a in agg.values())
-            for kind, (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                table_rows.append(dict(kernel=KIND_NAMES[kind], launches=cnt, total_us=round(ms * 1e3, 1),
-                                       avg_us=round(ms * 1e3 / cnt, 2), share=round(ms / total_ms, 3),
-                                       gflop=round(fl / 1e9, 4), mbytes=round(by / 1e6, 2)))
-            kind, (cnt, ms, fl, by) = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = fl / (ms * 1e-3) / 1e12
-            names = dict(KIND_NAMES)
-            if plan.gemm_tile == 64:
-                names[0] = 'gemm_mfma_kernel'            # plans with >= 6 clips per launch use the 64x64-tile GEMM
-            for r in table_rows:
-                if r['kernel'] == 'gemm_kernel':
-                    r['kernel'] = names[0]
-            roof = dict(bound='mfma', kernel=names[kind], launches_per_iter=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
-                        flop_per_launch=fl / cnt, achieved=achieved, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / PEAK_F32_TFLOPS, traffic=pmc_traffic(names[kind], K),
-                        clips_per_launch=K,
-                        whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
-                                             achieved_tflops=algorithmic_flops_per_iter(**CLIP) / (dt / args.steps) / 1e12))
-            if args.breakdown:
-                for r in table_rows:
-                    print(json.dumps(r), file=sys.stderr)
+            roof, table_rows = roofline_leg(plan, nat, params, gparams, xp, xu, K, dt / args.steps, args.breakdown)
 
     ips = world * args.steps / dt
     out = dict(metric='style-transfer opt iters/sec', value=ips, unit='iters/s', n_gpus=world, steps=args.steps,
@@ -296,12 +379,15 @@ def main():
                                     'step, Adam+StepLR every iter_size steps',
                            clips_per_gpu=B, iter_size=iter_size, hip_graph=graph_pair is not None,
                            accumulation=('batched plan, %d clips per launch' % K) if batched else '2 concurrent streams',
-                           launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 4,      # + memset, 3 loss kernels
+                           launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 3,      # + 3 loss kernels
                            parallelism=f'dp{world} ({"RCCL" if args.backend == "nccl" else args.backend} all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
                            device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))
     if rank == 0:
         out['roofline'] = roof
         out['kernel_breakdown'] = table_rows
+        if world == 1 and B == 1 and not batched and args.batched_clips > 1:
+            del plan, ws                     # the one-clip workspaces are no longer needed
+            out['batched'] = batched_leg(native, nat, dev, flat, args.batched_clips, args.batched_passes, 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(flat, table, clip, args.cpu_seconds)
         print(json.dumps(out))
