@@ -22,6 +22,22 @@
 #ifndef MST_LDS_BARRIER
 #define MST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// Exchange through a WAVE-PRIVATE LDS region: the DS operations of one wave execute in issue order, so a wave's reads see
+// its own lanes' earlier writes without an s_barrier; this only keeps the compiler from moving LDS accesses across the
+// point (no instruction is emitted).  The interpreter maps it to a real wave barrier (its lanes are separate fibers).
+// scheduling fence: keeps hipcc from hoisting a fully unrolled loop's LDS reads far ahead of their use (it did: 512 VGPRs
+// and scratch spills in the applier's backward); no instruction is emitted
+#ifndef MST_SCHED_FENCE
+#define MST_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef MST_WAVE_SYNC
+#define MST_WAVE_SYNC()                                            \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+        __builtin_amdgcn_wave_barrier();                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+    } while (0)
+#endif
 
 // ---- piano-roll constants (style/model.py:13-25)
 #define NF 10       // beat fractions
@@ -138,9 +154,13 @@ struct NotesDesc {
     int64_t x_off; int32_t x_space;  // ME: pitched input
     int64_t ml_off;              // PSA: (Q*F*56, ML)
     int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)
-    int64_t out_off;             // ME: mel_c (P,F,56,W); PSA: (P,F,56,5)
+    int64_t out_off;             // ME: melody (Q,F,56,W), the channels already combined; PSA: (P,F,56,5)
     int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;
-    int64_t slab_off; int32_t slab_stride; int32_t nblk;
+    int64_t slab_off; int32_t slab_stride; int32_t nblk;    // one slab row per WAVE: 4 * nblk rows
+    // ME only: the channel combine (style/model.py:296,796-815) is fused in.  nwc waves per channel leave partial sums:
+    int32_t nwc;                 // <= 64
+    int64_t part_off;            // [SP_TMP] forward: C*nwc partial sums of squares; backward: C*nwc partial a_c, then nwc partial b
+    int64_t stats_off;           // [SP_TMP] n_c (C floats), S
 };
 
 // ---- row-wise tiny Linear: y[r, :] = act(W x[r, :] + b) with K_in <= 8 and N_out <= 20 over very many rows
@@ -193,7 +213,9 @@ int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Ba
 int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 // `count` descriptors of identical shape (the clips of a batched plan), blockIdx.y = descriptor
+int launch_me_sumsq(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+int launch_me_bwd_reduce(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);

@@ -7,183 +7,330 @@
 // every note is one lane, the octave/degree rows of the position sit in LDS, the tiny weights
 // are LDS-broadcast, and nothing but the final 8 (or 5) outputs per note touches HBM.
 //
-// Backward kernels recompute the cheap per-note activations instead of saving them, stage the
-// per-note gradient vectors of one (position, fraction) in LDS, and then run "role" threads:
-// one lane per weight-gradient element (kept in a register across the workgroup's whole
-// grid-stride loop, one slab row per workgroup at the end) and one lane per octave / degree
-// gradient element (7- or 8-term LDS sums).  No float atomics; summation order is fixed.
+// Backward kernels recompute the cheap per-note activations instead of saving them.  The melody
+// encoder's reductions over notes run on the matrix cores (three 16x16x4 f32 MFMA chains per sweep),
+// the applier's backward puts the hidden feature on the lane so that every reduction over notes is
+// a per-lane register accumulation; weight gradients leave one slab row per wave.  No float
+// atomics; summation order is fixed.
 #include "mst_common.h"
 
 __device__ __forceinline__ float lrelu(float z) { return z > 0.f ? z : z * LEAKY; }
 __device__ __forceinline__ float dlrelu(float y) { return y > 0.f ? 1.f : LEAKY; }
 
 // ============================================================================ MelodyEncoder
+// Per position p = (channel c, q = (bar, beat)) and note item (fraction f, note n = (octave o, degree dg)):
+//   cat = [ leaky(oct[p][o][:] + deg[p][dg][:]) (W) | leaky(channels_linear(x[p][f][n][:5])) (CW) ],  x_c = leaky(linear(cat)) (W)
+// and the channels are merged by combine() (style/model.py:296,796-815):
+//   n_c = sqrt(1 + sum x_c^2),  melody = sum_c x_c n_c / S,  S = sum_c n_c.
+// The per-channel tensor x_c (4.6 MB per clip at the bench shape, written once and re-read four times by the unfused
+// path) is never materialised: it is cheap to recompute (15 -> 8 Linear per note), so
+//   forward  = me_sumsq (partial sums of x_c^2 per channel)  +  me_notes_fwd (recompute x_c for every channel of a q, write melody)
+//   backward = me_bwd_reduce (partial a_c = sum g x_c, b = sum g melody)  +  me_notes_bwd (recompute, dx_c on the fly, gradients).
+// Work distribution: ONE WAVE PER POSITION, lane = note (56 of 64 lanes), loop over the 10 fractions; octave / degree rows
+// of the position sit in registers (o, dg are fixed per lane), the tiny weights in LDS (hoisted to registers by the compiler).
+// Backward reductions over notes run on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32): per sweep the wave stages its
+// per-note vectors transposed in a wave-private LDS region ([feature][note], row stride 66 => conflict-free fragment reads) and
+//   dW_linear | db_linear = gm^T [cat | 1],   dW_channels | db_channels = gc^T [x | 1],   d_oct | d_deg = onehot(o | dg)^T god
+// are three 16-step MFMA chains; accumulators persist in registers across sweeps / positions.  Partial sums meet in a
+// fixed order everywhere (per-lane serial, xor-butterfly, MFMA k order): results are bitwise reproducible, no float atomics.
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+#define NT_ROW 66                  // LDS row stride of the transposed staging: bank = 2*(lane&15) + (lane>>4) => conflict-free
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void ld_vec(const float* p, float (&v)[N]) {
+    static_assert(N % 4 == 0, "16-byte rows");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) { const float4 t = reinterpret_cast<const float4*>(p)[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+template <int N>
+__device__ __forceinline__ void st_vec(float* p, const float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+// the small weights of the melody encoder's note tail, staged once per workgroup
 template <int W, int CW>
-__global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
-    const NotesDesc d = dp[blockIdx.y];
+struct MeWeights {
+    static constexpr int KL = W + CW;
+    float wc[CW * NPF], bc[CW], wl[W * KL], bl[W];
+    __device__ __forceinline__ void load(const NotesDesc& d, const float* par, int tid) {
+        for (int i = tid; i < CW * NPF; i += 256) wc[i] = par[d.wc_off + i];
+        for (int i = tid; i < CW; i += 256) bc[i] = par[d.bc_off + i];
+        for (int i = tid; i < W * KL; i += 256) wl[i] = par[d.wl_off + i];
+        for (int i = tid; i < W; i += 256) bl[i] = par[d.bl_off + i];
+    }
+};
+
+// one note of one channel: cat (W + CW) and x_c (W)
+template <int W, int CW>
+__device__ __forceinline__ void me_item(const MeWeights<W, CW>& w, const float (&octv)[W], const float (&degv)[W], const float (&x5)[NPF],
+                                        float (&cat)[W + CW], float (&out)[W]) {
     constexpr int KL = W + CW;
-    __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL], bl_s[W];
-    __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
-    const int tid = threadIdx.x;
-    const float* par = b.p[SP_PAR];
-    for (int i = tid; i < CW * NPF; i += 256) wc_s[i] = par[d.wc_off + i];
-    for (int i = tid; i < CW; i += 256) bc_s[i] = par[d.bc_off + i];
-    for (int i = tid; i < W * KL; i += 256) wl_s[i] = par[d.wl_off + i];
-    for (int i = tid; i < W; i += 256) bl_s[i] = par[d.bl_off + i];
-    const float* x = b.p[d.x_space] + d.x_off;
-    float* ws = b.p[SP_WS];
-    const int P = d.C * d.Q;
-    for (int p = blockIdx.x; p < P; p += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < NOCT * W; i += 256) oct_s[i] = ws[d.oct_off + (int64_t)p * NOCT * W + i];
-        for (int i = tid; i < NDEG * W; i += 256) deg_s[i] = ws[d.deg_off + (int64_t)p * NDEG * W + i];
-        __syncthreads();
-        for (int item = tid; item < NF * NPN; item += 256) {
-            const int n = item % NPN, o = n / NDEG, dg = n - o * NDEG;
-            const float* xi = x + ((int64_t)p * NF * NPN + item) * NPF;
-            float x5[NPF];
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) x5[i] = xi[i];
-            float cat[KL];
+    for (int j = 0; j < W; ++j) cat[j] = lrelu(octv[j] + degv[j]);
 #pragma unroll
-            for (int j = 0; j < W; ++j) cat[j] = lrelu(oct_s[o * W + j] + deg_s[dg * W + j]);
+    for (int k = 0; k < CW; ++k) {
+        float z = w.bc[k];
 #pragma unroll
-            for (int k = 0; k < CW; ++k) {
-                float z = bc_s[k];
+        for (int i = 0; i < NPF; ++i) z = fmaf(w.wc[k * NPF + i], x5[i], z);
+        cat[W + k] = lrelu(z);
+    }
 #pragma unroll
-                for (int i = 0; i < NPF; ++i) z = fmaf(wc_s[k * NPF + i], x5[i], z);
-                cat[W + k] = lrelu(z);
-            }
-            float* out = ws + d.out_off + ((int64_t)p * NF * NPN + item) * W;
+    for (int j = 0; j < W; ++j) {
+        float z = w.bl[j];
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-                float z = bl_s[j];
-#pragma unroll
-                for (int i = 0; i < KL; ++i) z = fmaf(wl_s[j * KL + i], cat[i], z);
-                out[j] = lrelu(z);
-            }
-        }
+        for (int i = 0; i < KL; ++i) z = fmaf(w.wl[j * KL + i], cat[i], z);
+        out[j] = lrelu(z);
     }
 }
 
-template <int W, int CW>
-__global__ __launch_bounds__(256) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+__device__ __forceinline__ void ld_x5(const float* x, int64_t item, float (&x5)[NPF]) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) x5[i] = x[item * NPF + i];
+}
+
+// Reduction pass shared by forward and backward.  BWD = false: partial sums of x_c^2.  BWD = true: partial a_c = sum g x_c
+// and (channel-0 waves only) partial b = sum g melody.  Wave g of the grid serves channel g / nwc and the positions
+// q = g % nwc, + nwc, ...; lane 0 leaves one partial per wave.
+// (Fetching the next sweep's operands one sweep ahead was measured on MI355X and lost: the weights already occupy ~170
+// VGPRs, the extra live registers cost the second wave per SIMD, and these kernels then ran 1.6-2x slower.)
+template <int W, int CW, bool BWD>
+__global__ __launch_bounds__(256) void me_reduce_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
-    constexpr int KL = W + CW;
-    constexpr int R_WC = 0, R_BC = CW * NPF, R_WL = R_BC + CW, R_BL = R_WL + W * KL, NW = R_BL + W;
-    static_assert(NW <= 256 && (NOCT + NDEG) * W <= 256, "role count exceeds the workgroup");
-    __shared__ float wc_s[CW * NPF], bc_s[CW], wl_s[W * KL];
-    __shared__ float oct_s[NOCT * W], deg_s[NDEG * W];
-    // per-note vectors staged transposed ([feature][note], 16-byte aligned rows): lane-contiguous writes in the note phase,
-    // two 16-byte LDS reads per four FMAs in the role sums (see psa_notes_bwd_kernel)
-    constexpr int NTP = NPN + 4;
-    static_assert(NPN % 4 == 0, "notes per group");
-    __shared__ __attribute__((aligned(16))) float gm_t[W][NTP], gc_t[CW][NTP], cat_t[KL][NTP], x_t[NPF][NTP];
-    __shared__ float god_t[W][NTP];
+    __shared__ MeWeights<W, CW> wt;
     const int tid = threadIdx.x;
-    const float* par = b.p[SP_PAR];
-    for (int i = tid; i < CW * NPF; i += 256) wc_s[i] = par[d.wc_off + i];
-    for (int i = tid; i < CW; i += 256) bc_s[i] = par[d.bc_off + i];
-    for (int i = tid; i < W * KL; i += 256) wl_s[i] = par[d.wl_off + i];
+    wt.load(d, b.p[SP_PAR], tid);
+    __syncthreads();
+    const int lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
+    if (g >= d.C * d.nwc) return;                          // wave-uniform
+    const int c = g / d.nwc, i0 = g - c * d.nwc;
+    const bool valid = lane < NPN;
+    const int n = valid ? lane : NPN - 1, o = n / NDEG, dg = n - o * NDEG;
     const float* x = b.p[d.x_space] + d.x_off;
-    float* ws = b.p[SP_WS];
-    const int P = d.C * d.Q;
-    float wacc = 0.f;                       // this lane's weight-gradient element
-    for (int p = blockIdx.x; p < P; p += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < NOCT * W; i += 256) oct_s[i] = ws[d.oct_off + (int64_t)p * NOCT * W + i];
-        for (int i = tid; i < NDEG * W; i += 256) deg_s[i] = ws[d.deg_off + (int64_t)p * NDEG * W + i];
-        float odacc = 0.f;                  // this lane's octave / degree gradient element
+    const float* ws = b.p[SP_WS];
+    float acc = 0.f, accb = 0.f;
+    for (int q = i0; q < d.Q; q += d.nwc) {
+        const int64_t p = (int64_t)c * d.Q + q;
+        float octv[W], degv[W];
+        ld_vec<W>(ws + d.oct_off + (p * NOCT + o) * W, octv);
+        ld_vec<W>(ws + d.deg_off + (p * NDEG + dg) * W, degv);
         for (int f = 0; f < NF; ++f) {
-            __syncthreads();
-            // note phase on all four waves: wave w handles every note (lane = note) for the cat elements
-            // i in [w*IQ, w*IQ + IQ); the note's 8 output gradients are re-read by each wave (L1 hits)
-            if ((tid & 63) < NPN) {
-                constexpr int IQ = (KL + 3) / 4;
-                const int wv = tid >> 6, n = tid & 63, o = n / NDEG, dg = n - o * NDEG;
-                const int64_t pos = (int64_t)p * NF * NPN + f * NPN + n;
-                float x5[NPF];
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) x5[i] = x[pos * NPF + i];
-                float gm[W];
-#pragma unroll
-                for (int j = 0; j < W; ++j) gm[j] = b.p[SP_GRAD][d.g_out_off + pos * W + j] * dlrelu(ws[d.out_off + pos * W + j]);
-                if (wv == 0) {
-#pragma unroll
-                    for (int i = 0; i < NPF; ++i) x_t[i][n] = x5[i];
-#pragma unroll
-                    for (int j = 0; j < W; ++j) gm_t[j][n] = gm[j];
-                }
-#pragma unroll
-                for (int ii = 0; ii < IQ; ++ii) {
-                    const int i = wv * IQ + ii;
-                    if (i < KL) {
-                        float c;
-                        if (i < W) {
-                            c = lrelu(oct_s[o * W + i] + deg_s[dg * W + i]);
-                        } else {
-                            float z = bc_s[i - W];
-#pragma unroll
-                            for (int q = 0; q < NPF; ++q) z = fmaf(wc_s[(i - W) * NPF + q], x5[q], z);
-                            c = lrelu(z);
-                        }
-                        float g = 0.f;
-#pragma unroll
-                        for (int j = 0; j < W; ++j) g = fmaf(gm[j], wl_s[j * KL + i], g);
-                        g *= dlrelu(c);
-                        cat_t[i][n] = c;
-                        if (i < W) god_t[i][n] = g; else gc_t[i - W][n] = g;
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < NW) {
-                // a role lane sums pa[n] (* pb[n]) over the 56 notes, four notes per pair of 16-byte reads
-                const float4* pa;
-                const float4* pb = nullptr;
-                if (tid >= R_BL) {
-                    pa = reinterpret_cast<const float4*>(gm_t[tid - R_BL]);
-                } else if (tid >= R_WL) {
-                    pa = reinterpret_cast<const float4*>(gm_t[(tid - R_WL) / KL]);
-                    pb = reinterpret_cast<const float4*>(cat_t[(tid - R_WL) % KL]);
-                } else if (tid >= R_BC) {
-                    pa = reinterpret_cast<const float4*>(gc_t[tid - R_BC]);
-                } else {
-                    pa = reinterpret_cast<const float4*>(gc_t[tid / NPF]);
-                    pb = reinterpret_cast<const float4*>(x_t[tid % NPF]);
-                }
-                float a = 0.f;
-                if (pb) {
-#pragma unroll
-                    for (int m4 = 0; m4 < NPN / 4; ++m4) {
-                        const float4 u = pa[m4], v = pb[m4];
-                        a = fmaf(u.x, v.x, a); a = fmaf(u.y, v.y, a); a = fmaf(u.z, v.z, a); a = fmaf(u.w, v.w, a);
-                    }
-                } else {
-#pragma unroll
-                    for (int m4 = 0; m4 < NPN / 4; ++m4) { const float4 u = pa[m4]; a += u.x; a += u.y; a += u.z; a += u.w; }
-                }
-                wacc += a;
-            }
-            if (tid < NOCT * W) {
-                const int o = tid / W, j = tid % W;
+            float x5[NPF], cat[W + CW], out[W];
+            ld_x5(x, (p * NF + f) * NPN + n, x5);
+            me_item<W, CW>(wt, octv, degv, x5, cat, out);
+            if constexpr (!BWD) {
                 float a = 0.f;
 #pragma unroll
-                for (int dg = 0; dg < NDEG; ++dg) a += god_t[j][o * NDEG + dg];
-                odacc += a;
-            } else if (tid < (NOCT + NDEG) * W) {
-                const int dg = (tid - NOCT * W) / W, j = tid % W;
+                for (int j = 0; j < W; ++j) a = fmaf(out[j], out[j], a);
+                if (valid) acc += a;
+            } else {
+                const int64_t mi = ((int64_t)q * NF + f) * NPN + n;
+                float gv[W];
+                ld_vec<W>(b.p[SP_GRAD] + d.g_out_off + mi * W, gv);
                 float a = 0.f;
 #pragma unroll
-                for (int o = 0; o < NOCT; ++o) a += god_t[j][o * NDEG + dg];
-                odacc += a;
+                for (int j = 0; j < W; ++j) a = fmaf(gv[j], out[j], a);
+                if (valid) acc += a;
+                if (c == 0) {
+                    float mel[W];
+                    ld_vec<W>(ws + d.out_off + mi * W, mel);
+                    float bb = 0.f;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) bb = fmaf(gv[j], mel[j], bb);
+                    if (valid) accb += bb;
+                }
             }
         }
-        // sole writer of these rows: store, not read-modify-write
-        if (tid < NOCT * W) b.p[SP_GRAD][d.g_oct_off + (int64_t)p * NOCT * W + tid] = odacc;
-        else if (tid < (NOCT + NDEG) * W) b.p[SP_GRAD][d.g_deg_off + (int64_t)p * NDEG * W + (tid - NOCT * W)] = odacc;
     }
-    if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
+    acc = wave_sum64(acc);
+    if (lane == 0) b.p[SP_TMP][d.part_off + (int64_t)c * d.nwc + i0] = acc;
+    if (BWD && c == 0) {
+        accb = wave_sum64(accb);
+        if (lane == 0) b.p[SP_TMP][d.part_off + (int64_t)d.C * d.nwc + i0] = accb;
+    }
+}
+
+// melody[q] = sum_c x_c[q] n_c / S: one wave per (q, half of the fractions), all channels recomputed; the first wave
+// also leaves n_c, S for the backward
+#define ME_FH 2
+template <int W, int CW>
+__global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc d = dp[blockIdx.y];
+    __shared__ MeWeights<W, CW> wt;
+    __shared__ float nc_s[4][COMBINE_MAXC + 1];
+    const int tid = threadIdx.x;
+    wt.load(d, b.p[SP_PAR], tid);
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, gw = blockIdx.x * 4 + wv;
+    const int q = gw / ME_FH, fh = gw - q * ME_FH;
+    if (q >= d.Q) return;                                   // wave-uniform
+    float* tmp = b.p[SP_TMP];
+    float S = 0.f;
+    for (int c = 0; c < d.C; ++c) {                        // every wave re-sums the partials in the same order
+        const float v = wave_sum64(lane < d.nwc ? tmp[d.part_off + (int64_t)c * d.nwc + lane] : 0.f);
+        const float nc = sqrtf(1.f + v);
+        S += nc;
+        if (lane == 0) { nc_s[wv][c] = nc; if (gw == 0) tmp[d.stats_off + c] = nc; }
+    }
+    if (gw == 0 && lane == 0) tmp[d.stats_off + d.C] = S;
+    MST_WAVE_SYNC();
+    const bool valid = lane < NPN;
+    const int n = valid ? lane : NPN - 1, o = n / NDEG, dg = n - o * NDEG;
+    const float* x = b.p[d.x_space] + d.x_off;
+    float* ws = b.p[SP_WS];
+    constexpr int F0 = NF / ME_FH;
+    const int f_begin = fh * F0, f_end = fh == ME_FH - 1 ? NF : f_begin + F0;
+    for (int f = f_begin; f < f_end; ++f) {
+        float acc[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] = 0.f;
+        for (int c = 0; c < d.C; ++c) {
+            const int64_t p = (int64_t)c * d.Q + q;
+            float octv[W], degv[W], x5[NPF], cat[W + CW], out[W];
+            ld_vec<W>(ws + d.oct_off + (p * NOCT + o) * W, octv);
+            ld_vec<W>(ws + d.deg_off + (p * NDEG + dg) * W, degv);
+            ld_x5(x, (p * NF + f) * NPN + n, x5);
+            me_item<W, CW>(wt, octv, degv, x5, cat, out);
+            const float nc = nc_s[wv][c];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[j] = fmaf(out[j], nc, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] = acc[j] / S;
+        if (valid) st_vec<W>(ws + d.out_off + (((int64_t)q * NF + f) * NPN + n) * W, acc);
+    }
+}
+
+// One wave per (position, half of the fractions): the two waves of a position are neighbours in one workgroup and meet
+// once, at the end of the position, to add their octave / degree partial sums (fixed order: half 0 + half 1).
+template <int W, int CW>
+__global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+    const NotesDesc d = dp[blockIdx.y];
+    constexpr int KL = W + CW;
+    constexpr int R_WC = 0, R_BC = CW * NPF, R_WL = R_BC + CW, R_BL = R_WL + W * KL;
+    static_assert(KL + 1 <= 16 && W <= 16 && CW <= 16, "one 16x16 MFMA tile per product");
+    // transposed staging rows of one wave: gm (W) | cat (KL) | gc (CW) | x (5) | god (W)
+    constexpr int T_GM = 0, T_CAT = W, T_GC = W + KL, T_X = T_GC + CW, T_GOD = T_X + NPF, T_ROWS = T_GOD + W;
+    __shared__ MeWeights<W, CW> wt;
+    __shared__ float tr[4][T_ROWS][NT_ROW];
+    __shared__ float od_s[2][4][64];                       // octave | degree partial sums of the odd wave of each pair
+    const int tid = threadIdx.x;
+    wt.load(d, b.p[SP_PAR], tid);
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, pair = wv >> 1, fh = wv & 1;
+    const bool valid = lane < NPN;
+    const int n = valid ? lane : NPN - 1, o = n / NDEG, dg = n - o * NDEG;
+    const float* x = b.p[d.x_space] + d.x_off;
+    const float* ws = b.p[SP_WS];
+    const float* tmp = b.p[SP_TMP];
+    float* gr = b.p[SP_GRAD];
+    float (*t)[NT_ROW] = tr[wv];
+    const int r = lane & 15, kh = lane >> 4;               // MFMA fragment coordinates: row / column r, k = 4 s + kh
+    // one-hot A operand of the octave | degree reduction: item 4 s + kh is note (o', dg'); rows 0..7 octaves, 8..14 degrees
+    // (kept as a 16-bit mask: sixteen float registers would cost the second wave per SIMD)
+    unsigned ohmask = 0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int it = 4 * s + kh, io = it / NDEG, idg = it - io * NDEG;
+        if (it < NPN && (r < NOCT ? io == r : idg == r - NOCT)) ohmask |= 1u << s;
+    }
+    const float S = tmp[d.stats_off + d.C];
+    const float bsum = wave_sum64(lane < d.nwc ? tmp[d.part_off + (int64_t)d.C * d.nwc + lane] : 0.f);
+    nt_f32x4 accW = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+    const int P = d.C * d.Q;
+    constexpr int F0 = NF / 2;
+    const int f_begin = fh * F0, f_end = fh ? NF : F0;
+    // the loop is workgroup-uniform (both waves of a pair, and both pairs, run the same trip count) because of the
+    // barrier at the end of a position; a pair beyond P computes nothing
+    const int trips = (P + gridDim.x * 2 - 1) / (gridDim.x * 2);
+    for (int tIdx = 0; tIdx < trips; ++tIdx) {
+        const int p = (tIdx * gridDim.x + blockIdx.x) * 2 + pair;
+        const bool live = p < P;
+        nt_f32x4 accO = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const int c = p / d.Q, q = p - c * d.Q;
+            const float nc = tmp[d.stats_off + c];
+            const float ac = wave_sum64(lane < d.nwc ? tmp[d.part_off + (int64_t)c * d.nwc + lane] : 0.f);
+            const float k2 = (ac - bsum) / S;
+            float octv[W], degv[W];
+            ld_vec<W>(ws + d.oct_off + ((int64_t)p * NOCT + o) * W, octv);
+            ld_vec<W>(ws + d.deg_off + ((int64_t)p * NDEG + dg) * W, degv);
+            for (int f = f_begin; f < f_end; ++f) {
+                float x5[NPF], cat[KL], out[W], gv[W];
+                ld_x5(x, ((int64_t)p * NF + f) * NPN + n, x5);
+                ld_vec<W>(gr + d.g_out_off + (((int64_t)q * NF + f) * NPN + n) * W, gv);
+                me_item<W, CW>(wt, octv, degv, x5, cat, out);
+                float gm[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) {              // combine backward, then the linear's leaky
+                    const float dx = gv[j] * nc / S + k2 * (out[j] / nc);
+                    gm[j] = valid ? dx * dlrelu(out[j]) : 0.f;
+                }
+                MST_WAVE_SYNC();                           // the previous sweep's fragment reads are done
+#pragma unroll
+                for (int j = 0; j < W; ++j) t[T_GM + j][lane] = gm[j];
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    float gsum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) gsum = fmaf(gm[j], wt.wl[j * KL + i], gsum);
+                    gsum *= dlrelu(cat[i]);
+                    t[T_CAT + i][lane] = cat[i];
+                    if (i < W) t[T_GOD + i][lane] = gsum; else t[T_GC + i - W][lane] = gsum;
+                }
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) t[T_X + i][lane] = x5[i];
+                MST_WAVE_SYNC();
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = 4 * s + kh;
+                    const float a1 = r < W ? t[T_GM + (r < W ? r : 0)][k] : 0.f;
+                    const float b1 = r < KL ? t[T_CAT + (r < KL ? r : 0)][k] : (r == KL ? 1.f : 0.f);
+                    accW = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accW, 0, 0, 0);
+                    const float a2 = r < CW ? t[T_GC + (r < CW ? r : 0)][k] : 0.f;
+                    const float b2 = r < NPF ? t[T_X + (r < NPF ? r : 0)][k] : (r == NPF ? 1.f : 0.f);
+                    accC = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, accC, 0, 0, 0);
+                    const float b3 = r < W ? t[T_GOD + (r < W ? r : 0)][k] : 0.f;
+                    accO = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((ohmask >> s) & 1u), b3, accO, 0, 0, 0);
+                    if ((s & 3) == 3) MST_SCHED_FENCE();
+                }
+            }
+        }
+        if (fh) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) od_s[pair][rr][lane] = accO[rr];
+        }
+        __syncthreads();
+        // D[row = 4 kh + rr][col = r]: rows 0..7 -> d_oct[o][j = r], rows 8..14 -> d_deg[dg][j = r]; sole writer of these rows
+        if (live && !fh && r < W) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 4 * kh + rr;
+                const float v = accO[rr] + od_s[pair][rr][lane];
+                if (row < NOCT) gr[d.g_oct_off + ((int64_t)p * NOCT + row) * W + r] = v;
+                else if (row < NOCT + NDEG) gr[d.g_deg_off + ((int64_t)p * NDEG + row - NOCT) * W + r] = v;
+            }
+        }
+        __syncthreads();
+    }
+    // one slab row per wave: channels_linear.{weight,bias}, linear.{weight,bias} in parameter order
+    float* slab = b.p[SP_TMP] + d.slab_off + (int64_t)(blockIdx.x * 4 + wv) * d.slab_stride;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * kh + rr;
+        if (row < W) {
+            if (r < KL) slab[R_WL + row * KL + r] = accW[rr]; else if (r == KL) slab[R_BL + row] = accW[rr];
+        }
+        if (row < CW) {
+            if (r < NPF) slab[R_WC + row * NPF + r] = accC[rr]; else if (r == NPF) slab[R_BC + row] = accC[rr];
+        }
+    }
 }
 
 // ============================================================================ PitchedStyleApplier
@@ -259,134 +406,206 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
     }
 }
 
+// Backward of the applier's note tail.  Per row (channel c, qf) and note n = (o, dg):
+//   h[j] = leaky(lo[o][j] + ld[dg][j]) (30),  z[i] = b[i] + sum_j W[i][j] h[j] + sum_k W[i][30 + k] ml[qf][n][k],  y = act(z) (5).
+// Lane = hidden feature j, TWO rows per wave (lanes 0..29: channel 2 cp, lanes 32..61: channel 2 cp + 1), one wave per qf.
+// With the feature on the lane every reduction over notes is a per-lane register accumulation — no cross-lane sums, no
+// role phase, no workgroup barrier in the loop: the lane keeps lo[0..7][j], ld[0..6][j] and W[0..4][j] in registers, the
+// row's 56 x 5 output gradients dz are staged once in a wave-private LDS region and read back as wave-uniform (broadcast)
+// 16-byte reads, and for every note (o, dg compile-time constants of the unrolled loop)
+//   dh = sum_i dz[i] W[i][j];  dW[i][j] += dz[i] h;  g = dh leaky'(h);  d_lo[o][j] += g;  d_ld[dg][j] += g.
+// The melody-linear columns need only the CHANNEL SUM of dz (ml does not depend on the channel):
+//   g_ml[qf][n][k] = sum_i dzsum[n][i] W[i][30 + k],  dW[i][30 + k] += dzsum[n][i] ml[qf][n][k],  db[i] += dzsum[n][i]
+// — a short second phase per qf with lane = (k, note group).  One slab row of weight gradients per wave.
 template <int ML>
-__global__ __launch_bounds__(256) void psa_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+__global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
-    constexpr int NW = NPF * KL + NPF;                 // linear.weight (5 x KL) then linear.bias (5)
     constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW;
-    constexpr int NTP = NPN + 4;                       // note-major rows, 16-byte aligned, 8 lanes of a b128 read span all banks
-    static_assert(NW <= 256 && NPN % 4 == 0, "role count exceeds the workgroup");
-    __shared__ float w_s[NPF * KL];
-    __shared__ float lo_s[NLO], ld_s[NLD];
-    // per-note vectors are staged TRANSPOSED ([feature][note]): the note phase writes lane-contiguous, and a role lane
-    // reads four notes of its two operands with two 16-byte LDS reads per four FMAs (it was two 4-byte reads per FMA:
-    // PMC showed one LDS instruction per 1.8 VALU instructions)
-    __shared__ __attribute__((aligned(16))) float dz_t[NPF][NTP];
-    __shared__ __attribute__((aligned(16))) float h_t[PSA_HW][NTP];
-    __shared__ __attribute__((aligned(16))) float ml_t[ML][NTP];
-    __shared__ float dh_t[PSA_HW][NTP];
-    const int tid = threadIdx.x;
+    constexpr int ROWE = NPN * NPF;                       // 280 output elements per row
+    constexpr int NSLOT = (2 * ROWE + 63) / 64;            // flat (row A | row B) elements per lane
+    constexpr int NG = 64 / ML;                            // note groups of the melody phase
+    constexpr int NT = (NPN + NG - 1) / NG;
+    __shared__ __attribute__((aligned(16))) float dz_s[4][2][NPN][8];      // [wave][row A|B][note][5 used of 8]
+    __shared__ __attribute__((aligned(16))) float dzs_s[4][2][NPN][8];     // channel sums, same layout
+    __shared__ float lo_s[4][NOCT][64];                                     // the row pair's octave rows, [octave][lane]
+    __shared__ float red_s[4][NPF][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, jl = lane & 31;
+    const bool jvalid = jl < PSA_HW;
+    const int j = jvalid ? jl : PSA_HW - 1;
     const float* par = b.p[SP_PAR];
-    for (int i = tid; i < NPF * KL; i += 256) w_s[i] = par[d.wl_off + i];
-    float* ws = b.p[SP_WS];
+    const float* ws = b.p[SP_WS];
+    float* gr = b.p[SP_GRAD];
     const int QF = d.Q * NF;
-    // note phase on all four waves: lane = note, wave w handles hidden features j in [8w, 8w + 8) and the melody-linear
-    // gradients k in [w*KQ, w*KQ + KQ); the note's 5 output gradients are re-read by each wave (L1 hits)
-    constexpr int JQ = (PSA_HW + 3) / 4, KQ = (ML + 3) / 4;
-    const int wv = tid >> 6, n = tid & 63, o = n / NDEG, dg = n - o * NDEG;
-    float wacc = 0.f;
-    // the octave | degree rows of the NEXT (qf, c) are fetched into two registers per lane while the current one is
-    // processed, so their global-load latency is not paid at every barrier
-    constexpr int NOD = NLO + NLD;                      // 450 <= 2 * 256
-    float od0 = 0.f, od1 = 0.f;
-    auto fetch_od = [&](int64_t row) {
-        od0 = tid < NLO ? ws[d.oct_off + row * NLO + tid] : ws[d.deg_off + row * NLD + (tid - NLO)];
-        if (tid + 256 < NOD) od1 = ws[d.deg_off + row * NLD + (tid + 256 - NLO)];
+    float wj[NPF], dwj[NPF];                               // W[i][j] and its gradient
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) { wj[i] = par[d.wl_off + i * KL + j]; dwj[i] = 0.f; }
+    // melody phase: lane = (k, note group g3)
+    const int k = lane % ML, g3 = lane / ML;
+    const bool mact = g3 < NG;
+    float wm[NPF], dwm[NPF], dbm[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) { wm[i] = par[d.wl_off + i * KL + PSA_HW + k]; dwm[i] = 0.f; dbm[i] = 0.f; }
+    float* dzf = &dz_s[wv][0][0][0];                      // flat views: row A at [0, 448), row B at [448, 896) (8 floats per note)
+    float* dzsf = &dzs_s[wv][0][0][0];
+    // per-lane constants of the cooperative dz staging: flat element e = lane + 64 q of (row A | row B)
+    int e_lds[NSLOT], e_off[NSLOT];
+    bool e_dur[NSLOT], e_rowb[NSLOT], e_in[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+        const int e = lane + 64 * q;
+        const int hb = e >= ROWE ? 1 : 0, ee = e - hb * ROWE;
+        const int nn = ee / NPF, ii = ee - nn * NPF;
+        e_in[q] = e < 2 * ROWE; e_rowb[q] = hb != 0; e_dur[q] = ii == 0;
+        e_off[q] = e_in[q] ? ee : 0;
+        e_lds[q] = hb * (NPN * 8) + nn * 8 + ii;
+    }
+    // Everything a row pair reads from global memory, fetched ONE PAIR AHEAD of its use (two waves per SIMD cannot hide a
+    // dependent load behind another wave's work): degree rows, octave rows, predictions and their gradients.
+    struct PairIn { float ld[NDEG], lo[NOCT], y[NSLOT], dy[NSLOT]; };
+    auto fetch = [&](int qf, int c0, PairIn& r) {
+        const int c = c0 + half;
+        const int64_t row = (int64_t)(c < d.C ? c : d.C - 1) * QF + qf;
+#pragma unroll
+        for (int q = 0; q < NDEG; ++q) r.ld[q] = ws[d.deg_off + row * NLD + q * PSA_HW + j];
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) r.lo[o] = ws[d.oct_off + row * NLO + o * PSA_HW + j];
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            const int cc = c0 + (e_rowb[q] ? 1 : 0);
+            const int64_t pos = ((int64_t)(cc < d.C ? cc : 0) * QF + qf) * ROWE + e_off[q];
+            r.y[q] = ws[d.out_off + pos];
+            r.dy[q] = gr[d.g_out_off + pos];
+        }
     };
-    if ((int)blockIdx.x < QF) fetch_od((int64_t)blockIdx.x);
-    // this lane's role: element (ri, rj) of linear.weight, or bias element ri
-    const int ri = tid < NPF * KL ? tid / KL : tid - NPF * KL;
-    const int rj = tid < NPF * KL ? tid % KL : -1;
-    for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
-        __syncthreads();
-        for (int i = tid; i < NPN * ML; i += 256) ml_t[i % ML][i / ML] = ws[d.ml_off + (int64_t)qf * NPN * ML + i];
-        float gml[KQ];
+    const int stride = gridDim.x * 4;
+    int qf = blockIdx.x * 4 + wv, c0 = 0;
+    bool have = qf < QF;
+    PairIn cur;
+    if (have) fetch(qf, 0, cur);
+    float dzsum[NSLOT];
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) gml[k] = 0.f;
-        for (int c = 0; c < d.C; ++c) {
-            const int64_t row = (int64_t)c * QF + qf;
-            __syncthreads();
-            if (tid < NLO) lo_s[tid] = od0; else ld_s[tid - NLO] = od0;
-            if (tid + 256 < NOD) ld_s[tid + 256 - NLO] = od1;
-            __syncthreads();
-            if (c + 1 < d.C) fetch_od((int64_t)(c + 1) * QF + qf);
-            else if (qf + (int)gridDim.x < QF) fetch_od((int64_t)(qf + gridDim.x));
-            if (n < NPN) {
-                const int64_t pos = row * NPN + n;
-                float dz[NPF];
+    for (int q = 0; q < NSLOT; ++q) dzsum[q] = 0.f;
+    while (have) {                                         // wave-uniform
+        int nqf = qf, nc0 = c0 + 2;
+        if (nc0 >= d.C) { nc0 = 0; nqf = qf + stride; }
+        const bool nhave = nqf < QF;
+        PairIn nxt;
+        if (nhave) fetch(nqf, nc0, nxt);                   // in flight under this pair's arithmetic
+        const int c = c0 + half;
+        const bool rvalid = c < d.C;
+        const int64_t row = (int64_t)(rvalid ? c : d.C - 1) * QF + qf;
+        float dld[NDEG];
 #pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    const float y = ws[d.out_off + pos * NPF + i];
-                    const float dy = b.p[SP_GRAD][d.g_out_off + pos * NPF + i];
-                    dz[i] = dy * (i == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y));
-                    if (wv == 0) dz_t[i][n] = dz[i];
-                }
+        for (int q = 0; q < NDEG; ++q) dld[q] = 0.f;
+        MST_WAVE_SYNC();                                   // the previous pair's LDS reads are done
 #pragma unroll
-                for (int jj = 0; jj < JQ; ++jj) {
-                    const int j = wv * JQ + jj;
-                    if (j < PSA_HW) {
-                        const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
-                        float g = 0.f;
+        for (int o = 0; o < NOCT; ++o) lo_s[wv][o][lane] = cur.lo[o];
+        // dz = dy act'(y) of both rows (zeros for an absent row B)
 #pragma unroll
-                        for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + j], g);
-                        h_t[j][n] = h;
-                        dh_t[j][n] = g * dlrelu(h);
-                    }
-                }
+        for (int q = 0; q < NSLOT; ++q) {
+            const bool ok = e_in[q] && (c0 + (e_rowb[q] ? 1 : 0)) < d.C;
+            const float y = cur.y[q];
+            const float dzv = ok ? cur.dy[q] * (e_dur[q] ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y)) : 0.f;
+            if (e_in[q]) dzf[e_lds[q]] = dzv;
+            dzsum[q] += dzv;
+        }
+        MST_WAVE_SYNC();
+        const float* dzr = dzf + half * (NPN * 8);
+        float* glop = gr + d.g_oct_off + row * NLO + j;
+        // the octave loop is a REAL loop (a fully unrolled 56-note body made hipcc hoist every independent add / select to
+        // the top and spill 500 registers); the degree rows stay in registers, the octave rows come from LDS
+#pragma unroll 1
+        for (int o = 0; o < NOCT; ++o) {
+            const float lo = lo_s[wv][o][lane];
+            float dlo = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < KQ; ++kk) {
-                    const int k = wv * KQ + kk;
-                    if (k < ML) {
-                        float g = 0.f;
-#pragma unroll
-                        for (int i = 0; i < NPF; ++i) g = fmaf(dz[i], w_s[i * KL + PSA_HW + k], g);
-                        gml[kk] += g;
-                    }
-                }
+            for (int dg = 0; dg < NDEG; ++dg) {
+                const float* zr = dzr + (o * NDEG + dg) * 8;
+                const float4 z4 = *reinterpret_cast<const float4*>(zr);
+                const float z5 = zr[4];
+                const float xh = lo + cur.ld[dg];
+                const float slope = xh > 0.f ? 1.f : LEAKY;
+                const float h = xh * slope;
+                float dh = z4.x * wj[0];
+                dh = fmaf(z4.y, wj[1], dh); dh = fmaf(z4.z, wj[2], dh); dh = fmaf(z4.w, wj[3], dh); dh = fmaf(z5, wj[4], dh);
+                dwj[0] = fmaf(z4.x, h, dwj[0]); dwj[1] = fmaf(z4.y, h, dwj[1]); dwj[2] = fmaf(z4.z, h, dwj[2]);
+                dwj[3] = fmaf(z4.w, h, dwj[3]); dwj[4] = fmaf(z5, h, dwj[4]);
+                const float g = dh * slope;
+                dlo += g; dld[dg] += g;
             }
-            __syncthreads();
-            if (tid < NW) {
-                const float4* pa = reinterpret_cast<const float4*>(dz_t[ri]);
-                float a = 0.f;
-                if (rj < 0) {
+            if (jvalid && rvalid) glop[o * PSA_HW] = dlo;      // sole writer of this row's octave / degree gradients
+        }
+        if (jvalid && rvalid) {
 #pragma unroll
-                    for (int m4 = 0; m4 < NPN / 4; ++m4) { const float4 x = pa[m4]; a += x.x; a += x.y; a += x.z; a += x.w; }
-                } else {
-                    const float4* pb = reinterpret_cast<const float4*>(rj < PSA_HW ? h_t[rj] : ml_t[rj - PSA_HW]);
+            for (int q = 0; q < NDEG; ++q) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dld[q];
+        }
+        if (nc0 == 0) {
+            // ---- last pair of this qf: the melody-linear columns from the channel sums
+            MST_WAVE_SYNC();
 #pragma unroll
-                    for (int m4 = 0; m4 < NPN / 4; ++m4) {
-                        const float4 x = pa[m4], y = pb[m4];
-                        a = fmaf(x.x, y.x, a); a = fmaf(x.y, y.y, a); a = fmaf(x.z, y.z, a); a = fmaf(x.w, y.w, a);
-                    }
-                }
-                wacc += a;
+            for (int q = 0; q < NSLOT; ++q) {
+                if (e_in[q]) dzsf[e_lds[q]] = dzsum[q];
+                dzsum[q] = 0.f;
             }
-            for (int r = tid; r < NLO + NLD; r += 256) {
-                float a = 0.f;
-                if (r < NLO) {
-                    const int oo = r / PSA_HW, j = r % PSA_HW;
+            MST_WAVE_SYNC();
+#pragma unroll 2
+            for (int tt = 0; tt < NT; ++tt) {
+                const int n = g3 + tt * NG;
+                const bool ok = mact && n < NPN;
+                const int nn = ok ? n : 0;
+                float s5[NPF];
 #pragma unroll
-                    for (int q = 0; q < NDEG; ++q) a += dh_t[j][oo * NDEG + q];
-                    b.p[SP_GRAD][d.g_oct_off + row * NLO + r] = a;      // sole writer of this row: store, not read-modify-write
-                } else {
-                    const int q = (r - NLO) / PSA_HW, j = (r - NLO) % PSA_HW;
+                for (int i = 0; i < NPF; ++i) s5[i] = dzsf[nn * 8 + i] + dzsf[NPN * 8 + nn * 8 + i];
+                const int64_t mi = ((int64_t)qf * NPN + nn) * ML + k;
+                const float mlv = ws[d.ml_off + mi];
+                float gm = s5[0] * wm[0];
 #pragma unroll
-                    for (int oo = 0; oo < NOCT; ++oo) a += dh_t[j][oo * NDEG + q];
-                    b.p[SP_GRAD][d.g_deg_off + row * NLD + (r - NLO)] = a;
+                for (int i = 1; i < NPF; ++i) gm = fmaf(s5[i], wm[i], gm);
+                if (ok) {
+                    gr[d.g_ml_off + mi] = gm;              // sole writer (all channels already summed)
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) { dwm[i] = fmaf(s5[i], mlv, dwm[i]); dbm[i] += s5[i]; }
                 }
             }
         }
-        if (n < NPN) {
-            float* g = b.p[SP_GRAD] + d.g_ml_off + ((int64_t)qf * NPN + n) * ML;
+        cur = nxt; qf = nqf; c0 = nc0; have = nhave;
+    }
+    // ---- one slab row per wave: linear.weight (5 x KL) then linear.bias (5); partial sums meet in a fixed order
+    float* slab = b.p[SP_TMP] + d.slab_off + (int64_t)(blockIdx.x * 4 + wv) * d.slab_stride;
+    float (*red)[64] = red_s[wv];
+    MST_WAVE_SYNC();
 #pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int k = wv * KQ + kk;
-                if (k < ML) g[k] = gml[kk];                            // sole writer (all channels summed above)
-            }
+    for (int i = 0; i < NPF; ++i) red[i][lane] = dwj[i];
+    MST_WAVE_SYNC();
+    if (lane < PSA_HW) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) slab[i * KL + lane] = red[i][lane] + red[i][lane + 32];
+    }
+    MST_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) red[i][lane] = dwm[i];
+    MST_WAVE_SYNC();
+    if (lane < ML) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            float a = red[i][lane];
+#pragma unroll
+            for (int gq = 1; gq < NG; ++gq) a += red[i][lane + gq * ML];
+            slab[i * KL + PSA_HW + lane] = a;
         }
     }
-    if (tid < NW) b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = wacc;
+    MST_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) red[i][lane] = dbm[i];
+    MST_WAVE_SYNC();
+    if (lane < NPF) {
+        float a = red[lane][0];
+#pragma unroll
+        for (int gq = 1; gq < NG; ++gq) a += red[lane][gq * ML];
+        slab[NPF * KL + lane] = a;
+    }
 }
 
 // ============================================================================ dispatch
@@ -405,9 +624,20 @@ bool notes_widths_supported(int W, int CW, int ML) {
     else if (h.ML == 14) hipLaunchKernelGGL((KERN<14>), GRID, BLOCK, 0, s, dev, b);                   \
     else return MST_ERR_UNSUPPORTED;
 
+#define ME_RED_DISPATCH(BWD, GRID, BLOCK)                                                              \
+    if (h.W == 8 && h.CW == 7) hipLaunchKernelGGL((me_reduce_kernel<8, 7, BWD>), GRID, BLOCK, 0, s, dev, b);     \
+    else if (h.W == 4 && h.CW == 5) hipLaunchKernelGGL((me_reduce_kernel<4, 5, BWD>), GRID, BLOCK, 0, s, dev, b); \
+    else return MST_ERR_UNSUPPORTED;
+int launch_me_sumsq(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
+    ME_RED_DISPATCH(false, dim3((h.C * h.nwc + 3) / 4, count), dim3(256));
+    return (int)hipGetLastError();
+}
+int launch_me_bwd_reduce(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
+    ME_RED_DISPATCH(true, dim3((h.C * h.nwc + 3) / 4, count), dim3(256));
+    return (int)hipGetLastError();
+}
 int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
-    int P = h.C * h.Q;
-    ME_DISPATCH(me_notes_fwd_kernel, dim3(P < 2048 ? P : 2048, count), dim3(256));
+    ME_DISPATCH(me_notes_fwd_kernel, dim3((h.Q * ME_FH + 3) / 4, count), dim3(256));
     return (int)hipGetLastError();
 }
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {

@@ -191,7 +191,8 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 // ------------------------------------------------------------------------------------------ plan
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
-enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B };
+enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B,
+       K_ME_SQ, K_ME_RED };
 struct Step { int kind, first, count, a, b, stage; };
 struct Acc { int space; int64_t lo, hi; bool w; };
 struct Op { int stage; std::vector<Step> fwd, bwd; };
@@ -271,9 +272,9 @@ struct mst_plan {
         return r;
     }
     NotesDesc reloc(NotesDesc n, int k) const {
-        const int64_t a = shift(SP_WS, k);
+        const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
         n.oct_off += a; n.deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
-        n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += shift(SP_TMP, k);
+        n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += t; n.part_off += t; n.stats_off += t;
         return n;
     }
 
@@ -640,27 +641,34 @@ void mst_plan::build() {
     T ycat = gather(E, rsCRT, {seg(me_bl, R * Tn, Tn, 1, 0), seg(me_br, 0, 1, 0, 0), seg(me_il, 1, 0, 0, 0)});
     T me_oct = linear(E, ycat, true, m + ".octave_linear", z.MEL * NOCT, ACT_LEAKY);
     T me_deg = linear(E, ycat, true, m + ".scale_degree_linear", z.MEL * NDEG, ACT_LEAKY);
-    T mel_c = newT(P_ * NF * NPN, z.MEL);
+    // note tail + channel combine fused (notes.hip): melody is written directly, the per-channel tensor never exists
+    T melody = newT(Q_ * NF * NPN, z.MEL, "melody");
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
         n.oct_off = me_oct.off; n.deg_off = me_deg.off; n.x_off = 0; n.x_space = SP_EXT0;
         n.wc_off = pt.off(m + ".channels_linear.weight"); n.bc_off = pt.off(m + ".channels_linear.bias");
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
-        n.out_off = mel_c.off; n.g_out_off = mel_c.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
+        n.out_off = melody.off; n.g_out_off = melody.off; n.g_oct_off = me_oct.off; n.g_deg_off = me_deg.off;
         const int nw = z.ME_CW * NPF + z.ME_CW + z.MEL * (z.MEL + z.ME_CW) + z.MEL;
-        // workgroups (= weight-gradient slabs) per clip: a batched plan gets its parallelism from the clips, and every
-        // slab is one more row the deferred reduction has to sum serially per weight element
+        // reduction passes: waves per channel (one partial each), a wave per position up to 64
+        // (the same count for every clip count: the grouping of the partial sums decides the last bits of n_c, and a clip's
+        // activations are bit-identical in one-clip and batched plans)
+        n.nwc = Q_ < 64 ? Q_ : 64;
+        n.part_off = tmp((int64_t)(C + 1) * n.nwc); n.stats_off = tmp(C + 1);
+        // backward: two waves per position (one per half of the fractions), two positions per workgroup up to the cap; every
+        // wave leaves one slab row for the deferred reduction
         const int me_blk = K() == 1 ? 256 : (2048 / K() < 4 ? 4 : (2048 / K() > 256 ? 256 : 2048 / K()));
-        n.nblk = P_ < me_blk ? P_ : me_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        const int want = (P_ + 1) / 2;
+        n.nblk = want < me_blk ? want : me_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk * 4);
         Op op; op.stage = E;
+        op.fwd.push_back(Step{K_ME_SQ, (int)notes.size(), 1, 0, 0});
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_ME_RED, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
         notes.push_back(n); ops.push_back(op);
         // channels_linear.{weight,bias}, linear.{weight,bias} are contiguous in the flat buffer
-        slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk});
+        slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk * 4});
     }
-    T melody = newT(Q_ * NF * NPN, z.MEL, "melody");
-    combine(E, mel_c.off, Q_ * NF * NPN, z.MEL, z.MEL, (int64_t)Q_ * NF * NPN * z.MEL, C, melody);
     stage_end[0] = act_top;
 
     // ================================================================= stage 2: predict_song_info
@@ -704,13 +712,15 @@ void mst_plan::build() {
         n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
         const int qf = Q_ * NF;
+        // forward: a workgroup per qf up to the cap.  backward: a wave per qf, four per workgroup, one slab row per wave
         const int psa_blk = K() == 1 ? 512 : (4096 / K() < 8 ? 8 : (4096 / K() > 512 ? 512 : 4096 / K()));
-        n.nblk = qf < psa_blk ? qf : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        const int want = (qf + 3) / 4;
+        n.nblk = want < psa_blk ? want : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk * 4);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
         notes.push_back(n); ops.push_back(op);
-        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk});
+        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk * 4});
     }
     if (U) {
         m = "unpitched_style_applier";
@@ -853,9 +863,34 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             }
             break;
         }
-        case K_ME_F: case K_ME_B: case K_PSA_F: case K_PSA_B: {
+        case K_ME_SQ: case K_ME_F: case K_ME_RED: case K_ME_B: {
             const NotesDesc& n = notes[s.first + i];
-            const bool me = s.kind == K_ME_F || s.kind == K_ME_B, bwd = s.kind == K_ME_B || s.kind == K_PSA_B;
+            const int64_t rows = (int64_t)n.C * n.Q, mel = (int64_t)n.Q * NF * NPN * n.W;
+            const int64_t nparts = (int64_t)(n.C + 1) * n.nwc;
+            acc_add(v, SP_WS, n.oct_off, rows * NOCT * n.W, false);
+            acc_add(v, SP_WS, n.deg_off, rows * NDEG * n.W, false);
+            if (s.kind == K_ME_SQ) acc_add(v, SP_TMP, n.part_off, nparts, true);
+            else if (s.kind == K_ME_F) {
+                acc_add(v, SP_TMP, n.part_off, nparts, false);
+                acc_add(v, SP_TMP, n.stats_off, n.C + 1, true);
+                acc_add(v, SP_WS, n.out_off, mel, true);
+            } else if (s.kind == K_ME_RED) {
+                acc_add(v, SP_WS, n.out_off, mel, false);
+                acc_add(v, SP_GRAD, n.g_out_off, mel, false);
+                acc_add(v, SP_TMP, n.part_off, nparts, true);
+            } else {
+                acc_add(v, SP_TMP, n.part_off, nparts, false);
+                acc_add(v, SP_TMP, n.stats_off, n.C + 1, false);
+                acc_add(v, SP_GRAD, n.g_out_off, mel, false);
+                acc_add(v, SP_GRAD, n.g_oct_off, rows * NOCT * n.W, true);
+                acc_add(v, SP_GRAD, n.g_deg_off, rows * NDEG * n.W, true);
+                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk * 4, true);
+            }
+            break;
+        }
+        case K_PSA_F: case K_PSA_B: {
+            const NotesDesc& n = notes[s.first + i];
+            const bool me = false, bwd = s.kind == K_PSA_B;
             const int64_t pos = (int64_t)n.C * n.Q * NF * NPN;
             const int64_t rows = me ? (int64_t)n.C * n.Q : (int64_t)n.C * n.Q * NF;
             const int ow = me ? NOCT * n.W : NOCT * 30, dw = me ? NDEG * n.W : NDEG * 30, outw = me ? n.W : NPF;
@@ -869,7 +904,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
                 acc_add(v, SP_GRAD, n.g_oct_off, rows * ow, true);
                 acc_add(v, SP_GRAD, n.g_deg_off, rows * dw, true);
                 if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
-                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
+                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk * 4, true);
             }
             break;
         }
@@ -905,7 +940,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             Step m = s0; m.count = 0;
             const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
             const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B;
-            const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B;
+            const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B || s0.kind == K_ME_SQ || s0.kind == K_ME_RED;
             if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
             else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
             else if (s0.kind == K_SEGRED) m.first = (int)s_segreds.size();
@@ -1103,6 +1138,8 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
     case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ROW_B: return launch_rowlin_bwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
+    case K_ME_SQ: return launch_me_sumsq(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
+    case K_ME_RED: return launch_me_bwd_reduce(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     case K_ME_F: return launch_me_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     case K_ME_B: return launch_me_notes_bwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
     case K_PSA_F: return launch_psa_notes_fwd(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
@@ -1250,12 +1287,15 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
             b += 4.0 * r.rows * (s.kind == K_ROW_F ? r.kin + r.nout : 2.0 * r.kin + 2.0 * r.nout + (r.xgrad ? r.kin : 0));
         }
         break;
-    case K_ME_F: case K_ME_B: {
+    case K_ME_SQ: case K_ME_F: case K_ME_RED: case K_ME_B: {
+        // algorithmic = the reference's (unfused) shapes; the recomputation the fused kernels do on top is not counted
         const NotesDesc& n = p->s_notes[s.first];
-        const double pos = (double)n.C * n.Q * NF * NPN * s.count;
+        const double pos = (double)n.C * n.Q * NF * NPN * s.count, mel = pos / n.C * n.W;
         const double per = 2.0 * n.W + 2.0 * n.CW * NPF + 2.0 * n.W * (n.W + n.CW);
-        f = pos * per * (s.kind == K_ME_F ? 1.0 : 3.0);
-        b = 4.0 * pos * (NPF + n.W * (s.kind == K_ME_F ? 1.0 : 2.0));
+        if (s.kind == K_ME_SQ) { f = pos * (per + 2.0 * n.W); b = 4.0 * pos * NPF; }
+        else if (s.kind == K_ME_F) { f = pos * 2.0 * n.W; b = 4.0 * (pos * NPF + mel); }
+        else if (s.kind == K_ME_RED) { f = pos * 2.0 * n.W; b = 4.0 * (pos * NPF + 2.0 * mel); }
+        else { f = pos * per * 2.0; b = 4.0 * (pos * NPF + mel); }
         break;
     }
     case K_PSA_F: case K_PSA_B: {
