@@ -101,12 +101,15 @@ int32_t mst_forward(const mst_plan* p, int32_t stage_mask, const float* params, 
 
 /* ---- backward of the same stages (what loss.backward() does, train-model.py:126).
  * Reads output gradients from the workspace gradient slots, accumulates parameter gradients
- * into gparams (+=, sum semantics — train-model.py:126,151-153). zero_first: clear the
- * stage's internal gradient slots before running (boundary slots are cleared by the caller
- * through mst_zero_grads). */
+ * into gparams (+=, sum semantics — train-model.py:126,151-153).  Call mst_zero_grads(stage_mask) before it;
+ * when a stage runs on its own the caller also writes (or clears) the gradient slots of that stage's outputs and
+ * of the stage-boundary tensors "style", "melody", "rhythm". */
 int32_t mst_backward(const mst_plan* p, int32_t stage_mask, const float* params, float* gparams,
                      float* ws, const float* pitched, const float* unpitched, mst_stream stream);
 int32_t mst_zero_grads(const mst_plan* p, int32_t stage_mask, float* ws, mst_stream stream);
+/* Gradient floats per clip that mst_zero_grads(stage_mask) clears: only ranges the plan's first-writer analysis could not
+ * prove written before they are read or accumulated into (every other gradient slot's first writer stores). */
+int64_t mst_plan_zero_floats(const mst_plan* p, int32_t stage_mask);
 
 /* ---- get_total_loss (style/model.py:935-997) with normalize flag; pointer based so that it
  * also serves the stand-alone Python get_total_loss. n_*_pos = number of note positions

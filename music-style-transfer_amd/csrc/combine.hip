@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDes
         for (int c = 0; c < d.Cn; ++c) {
             const float nc = nc_s[c];
             const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
-            gr[d.gx_off + (int64_t)c * d.cs + eo] += g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+            float* gx = gr + d.gx_off + (int64_t)c * d.cs + eo;
+            const float v = g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+            *gx = d.first ? v : *gx + v;
         }
     }
 }
@@ -231,7 +233,9 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
         for (int c = 0; c < d.Cn; ++c) {
             const float nc = nc_s[c];
             const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
-            gr[d.gx_off + (int64_t)c * d.cs + eo] += g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+            float* gx = gr + d.gx_off + (int64_t)c * d.cs + eo;
+            const float v = g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+            *gx = d.first ? v : *gx + v;
         }
     }
 }

@@ -82,7 +82,8 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
         if (bias) v += bias[n];
         cbase[(unsigned)(m * o.ldc + n)] = act_fwd(o.act, v, n);
     } else if constexpr (OK == OUT_ACCUM) {
-        cbase[(unsigned)(m * o.ldc + n)] += acc;
+        float* c = cbase + (unsigned)(m * o.ldc + n);
+        *c = o.first ? acc : *c + acc;              // first writer of this range in the pass: no read, nothing to clear
     } else if constexpr (OK == OUT_CONV) {          // m = (p, octave), n = out channel -> x1[p, n*8 + octave]
         cbase[(unsigned)((m >> 3) * o.ldc + n * NOCT + (m & 7))] = act_fwd(ACT_LEAKY, acc + bias[n], 0);
     } else if constexpr (OK == OUT_SLAB) {
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
         for (int q = 0; q < 8; ++q) acc += v[q];
     }
     for (; rr < r_end; ++rr) { acc += src[offset()]; advance(); }
-    if (d.nchunk == 1) b.p[SP_GRAD][d.dst_off + (int64_t)idx * d.dst_ld + w] += acc;
+    if (d.nchunk == 1) { float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld + w; *dst = d.first ? acc : *dst + acc; }
     else b.p[SP_TMP][d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width + w] = acc;
 }
 
@@ -542,7 +543,8 @@ __global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restri
         const float* pp = b.p[SP_TMP] + d.part_off + (int64_t)idx * d.nchunk * d.width + w;
         float acc = 0.f;
         for (int c = 0; c < d.nchunk; ++c) acc += pp[(int64_t)c * d.width];
-        b.p[SP_GRAD][d.dst_off + (int64_t)idx * d.dst_ld + w] += acc;
+        float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld + w;
+        *dst = d.first ? acc : *dst + acc;
     }
 }
 
@@ -585,6 +587,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
     part[g][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (g == 0 && i < e.count) b.p[SP_GPAR][e.dst + i] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(const ZeroChunk* __restrict__ ch, float* g, int64_t clip_stride) {
+    const ZeroChunk c = ch[blockIdx.x];
+    float* p = g + (int64_t)blockIdx.y * clip_stride + c.off;
+    for (int i = threadIdx.x; i < c.len; i += 256) p[i] = 0.f;
+}
+
+int launch_zero(const ZeroChunk* dev, int nchunks, int clips, float* grad_base, int64_t clip_stride, hipStream_t s) {
+    if (nchunks <= 0) return 0;
+    hipLaunchKernelGGL(zero_kernel, dim3(nchunks, clips), dim3(256), 0, s, dev, grad_base, clip_stride);
+    return (int)hipGetLastError();
 }
 
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s) {

@@ -86,6 +86,7 @@ struct OutSpec {
     int32_t bias_space;  // -1 = no bias
     int64_t bias_off;
     int64_t slab_stride; // OUT_SLAB: floats between k-splits
+    int32_t first;       // OUT_ACCUM: 1 = first writer of its (dense) target in this pass: store instead of += (no memset needed)
     int32_t wcols;       // OUT_SLAB: columns n < wcols are weights (row-major m*wcols+n); n == wcols is the bias column
     int32_t pb, pc;      // OUT_PERMW_SLAB: same column permutation as OPK_PERMW
 };
@@ -117,6 +118,7 @@ struct SegRedDesc {
     int32_t nchunk;      // chunks of 64 reduced rows; > 1 => partials at part_off, summed by stage 2
     int64_t part_off;    // [SP_TMP] nidx * nchunk * width
     int32_t blk_begin;   // first workgroup of this member inside its clip's block range of the (merged) launch
+    int32_t first;       // 1 = first writer of dst in this pass: store instead of +=
 };
 
 // ---- LSTM recurrence
@@ -144,6 +146,7 @@ struct CombineDesc {
     int64_t part_off;            // COMBINE_MAXBLK * (Cn+1) partials
     int64_t gx_off, gout_off;    // gradient slots (gx has the x layout)
     int32_t nblk;
+    int32_t first;               // backward: 1 = first writer of gx in this pass: store instead of +=
 };
 
 // ---- note-level fused stages
@@ -171,6 +174,7 @@ struct RowLinDesc {
     int64_t x_off, y_off;        // [SP_WS] rows x kin / rows x nout, contiguous; gradients at the same offsets in SP_GRAD
     int64_t w_off, b_off;        // [SP_PAR] weight (nout x kin) immediately followed by bias (nout)
     int64_t slab_off; int32_t slab_stride, nblk;   // [SP_TMP] one row of nout*kin + nout partial weight gradients per workgroup
+    int32_t first;               // backward: 1 = first writer of dx in this pass: store instead of +=
 };
 
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
@@ -234,6 +238,9 @@ bool rowlin_supported(int kin, int nout);
 int launch_rowlin_fwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);
 int launch_rowlin_bwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);
 int launch_slab_reduce(const SlabEntry* dev, const SlabBlock* blocks, int nblocks, Bases b, hipStream_t s);
+// gradient ranges still cleared before a backward pass (offsets into clip 0's slice of the gradient arena)
+struct ZeroChunk { int64_t off; int32_t len; int32_t pad; };
+int launch_zero(const ZeroChunk* dev, int nchunks, int clips, float* grad_base, int64_t clip_stride, hipStream_t s);
 bool notes_widths_supported(int W, int CW, int ML);
 
 #define GEMM_BM 32

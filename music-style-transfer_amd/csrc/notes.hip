@@ -756,7 +756,10 @@ __global__ __launch_bounds__(256) void rowlin_bwd_kernel(const RowLinDesc* __res
             for (int k = 0; k < KIN; ++k) st[NOUT + k][tid] = x[k];
             if (d.xgrad) {
                 float dx[KIN];
-                rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
+                if (d.first) {                          // first writer of dx in this pass: nothing to read
+#pragma unroll
+                    for (int k = 0; k < KIN; ++k) dx[k] = 0.f;
+                } else rl_load<KIN>(gx0 + (int64_t)row * KIN, dx);
 #pragma unroll
                 for (int k = 0; k < KIN; ++k) {
                     float a = 0.f;

@@ -20,6 +20,8 @@
 
 #include "mst_common.h"
 
+#define MST_ALIGN_UP(n) (((n) + 63) / 64 * 64)
+
 // ------------------------------------------------------------------------------------------ sizes
 static int mean_size(double a, double b, double factor = 1.0) { return (int)std::ceil(((a + b) / 2.0) * factor); }
 
@@ -194,7 +196,7 @@ struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
 enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B,
        K_ME_SQ, K_ME_RED };
 struct Step { int kind, first, count, a, b, stage; };
-struct Acc { int space; int64_t lo, hi; bool w; };
+struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
 static int stage_idx(int stage) { return stage == MST_STAGE_EXTRACT ? 0 : stage == MST_STAGE_INFO ? 1 : 2; }
@@ -220,6 +222,8 @@ struct mst_plan {
     SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabBlock> slab_blocks[3]; SlabBlock* d_slab_blocks[3] = {nullptr, nullptr, nullptr};
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
+    std::vector<ZeroChunk> zero_stage[3], zero_all;      // gradient ranges mst_zero_grads clears (clip 0 coordinates)
+    ZeroChunk* d_zero_stage[3] = {nullptr, nullptr, nullptr}; ZeroChunk* d_zero_all = nullptr;
     int err = 0;
     mst_plan_options opt{};       // as given to mst_plan_create_ex (zeros = defaults)
     int mfma = 0;                 // GEMM tiling of this plan: 1 = 64x64 tiles (batched, FLOP-bound plans), 0 = 32x32 split-K tiles (latency)
@@ -529,7 +533,8 @@ struct mst_plan {
     }
 
     void build();
-    void accesses(const Step& s, std::vector<Acc>& out) const;
+    void accesses(const Step& s, std::vector<Acc>& out, bool scheduled = false) const;
+    void first_writers(std::vector<Step>& list, size_t begin, bool per_stage, std::vector<Acc>& zero);
     void schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out, bool across_stages);
     void schedule();
     int upload();
@@ -743,10 +748,11 @@ void mst_plan::build() {
 // more than the deepest earlier step it conflicts with (RAW / WAR / WAW on overlapping ranges of the
 // activation, gradient or scratch arena; parameters and the borrowed note tensors are read-only).
 // All steps of one level, stage and kernel are then merged into one launch (blockIdx.y = member).
-static void acc_add(std::vector<Acc>& v, int space, int64_t lo, int64_t len, bool w) {
+static void acc_add(std::vector<Acc>& v, int space, int64_t lo, int64_t len, bool w, bool accum = false, bool dense = true) {
     if (space != SP_WS && space != SP_GRAD && space != SP_TMP) return;
     if (len <= 0) return;
-    v.push_back(Acc{space, lo, lo + len, w});
+    Acc a{space, lo, lo + len, w}; a.accum = accum; a.dense = dense;
+    v.push_back(a);
 }
 
 static void operand_acc(std::vector<Acc>& v, const Operand& o, int di, int dj, int ones) {
@@ -773,7 +779,15 @@ static void operand_acc(std::vector<Acc>& v, const Operand& o, int di, int dj, i
     }
 }
 
-void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
+void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) const {
+    // scheduled: s.first indexes the scheduled (per-clip relocated) descriptor arrays; clip 0's copies equal the originals
+    const std::vector<GemmDesc>& gemms = scheduled ? s_gemms : this->gemms;
+    const std::vector<GatherDesc>& gathers = scheduled ? s_gathers : this->gathers;
+    const std::vector<SegRedDesc>& segreds = scheduled ? s_segreds : this->segreds;
+    const std::vector<LstmDesc>& lstms = scheduled ? s_lstms : this->lstms;
+    const std::vector<CombineDesc>& combines = scheduled ? s_combines : this->combines;
+    const std::vector<NotesDesc>& notes = scheduled ? s_notes : this->notes;
+    const std::vector<RowLinDesc>& rowlins = scheduled ? s_rowlins : this->rowlins;
     for (int i = 0; i < s.count; ++i) {
         switch (s.kind) {
         case K_GEMM: {
@@ -782,7 +796,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             operand_acc(v, g.B, g.K, g.N, g.B.ones_at);
             const OutSpec& o = g.out;
             if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
-            else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
+            else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true, true, g.N == o.ldc || g.M == 1);
             else if (o.kind == OUT_CONV) acc_add(v, o.space, o.off, (int64_t)(g.M / NOCT) * o.ldc, true);
             else acc_add(v, o.space, o.off, o.slab_stride * g.ksplit, true);
             break;
@@ -802,7 +816,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             const SegRedDesc& r = segreds[s.first + i];
             const int64_t rows = (int64_t)r.d[0] * r.d[1] * r.d[2] * r.d[3];
             acc_add(v, SP_GRAD, r.src_off, rows * r.src_ld, false);
-            acc_add(v, SP_GRAD, r.dst_off, (int64_t)(r.nidx - 1) * r.dst_ld + r.width, true);
+            acc_add(v, SP_GRAD, r.dst_off, (int64_t)(r.nidx - 1) * r.dst_ld + r.width, true, true, r.width == r.dst_ld || r.nidx == 1);
             if (r.nchunk > 1) acc_add(v, SP_TMP, r.part_off, (int64_t)r.nidx * r.nchunk * r.width, true);
             break;
         }
@@ -847,7 +861,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
                 acc_add(v, SP_WS, c.out_off, n, false);
                 acc_add(v, SP_TMP, c.stats_off, 64, false);
                 acc_add(v, SP_GRAD, c.gout_off, n, false);
-                acc_add(v, SP_GRAD, lo - c.x_off + c.gx_off, span, true);
+                acc_add(v, SP_GRAD, lo - c.x_off + c.gx_off, span, true, true, span == (int64_t)c.Cn * n);
             }
             break;
         }
@@ -858,7 +872,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v) const {
             acc_add(v, SP_WS, r.y_off, ny, s.kind == K_ROW_F);
             if (s.kind == K_ROW_B) {
                 acc_add(v, SP_GRAD, r.y_off, ny, false);
-                if (r.xgrad) acc_add(v, SP_GRAD, r.x_off, nx, true);
+                if (r.xgrad) acc_add(v, SP_GRAD, r.x_off, nx, true, true, true);
                 acc_add(v, SP_TMP, r.slab_off, (int64_t)r.slab_stride * r.nblk, true);
             }
             break;
@@ -1009,6 +1023,67 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
     }
 }
 
+// Gradient slots without a memset.  Walk a scheduled backward list in launch order and decide, for every writer that can
+// accumulate (input-gradient GEMMs, segment reduces, combine backward, the row-wise Linear's dx), whether it is the FIRST
+// writer of a dense, so far untouched range of the gradient arena — then it stores (=) and nothing has to be cleared — or
+// lands on data written earlier in the pass — then it accumulates (+=).  Whatever is read, or accumulated into, without
+// having been written before (rows of an LSTM output nobody consumes, strided / partially covered targets) goes on the
+// zero list: the only ranges mst_zero_grads still clears.  (It was one memset of the whole arena: ~1 GB of writes per
+// 64-clip pass, more than the algorithmic bytes of the pass.)
+static bool covered(const std::vector<Acc>& have, int64_t lo, int64_t hi) {
+    // is [lo, hi) inside the union of the ranges in `have`?  (few dozen ranges: quadratic sweep is fine)
+    int64_t at = lo;
+    bool moved = true;
+    while (at < hi && moved) {
+        moved = false;
+        for (const Acc& a : have)
+            if (a.lo <= at && a.hi > at) { at = a.hi; moved = true; }
+    }
+    return at >= hi;
+}
+static bool touches(const std::vector<Acc>& have, int64_t lo, int64_t hi) {
+    for (const Acc& a : have) if (a.lo < hi && lo < a.hi) return true;
+    return false;
+}
+
+void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_stage, std::vector<Acc>& zero) {
+    std::vector<Acc> have;                               // ranges holding defined data at this point of the pass
+    auto external = [&](const char* name) {              // written by the caller / the loss before the pass starts
+        auto it = named.find(name);
+        if (it != named.end()) have.push_back(Acc{SP_GRAD, it->second.off, it->second.off + MST_ALIGN_UP((int64_t)it->second.rows * it->second.cols), true});
+    };
+    for (const char* nm : {"pitched_pred", "unpitched_pred", "instruments_pred", "mode_pred", "bpm_pred"}) external(nm);
+    if (per_stage) for (const char* nm : {"style", "melody", "rhythm"}) external(nm);      // seeded or cleared by the caller
+    const int copies = K();
+    for (size_t si = begin; si < list.size(); ++si) {
+        Step& m = list[si];
+        const int nm = m.kind == K_GEMM ? m.b : m.count / copies;
+        for (int q = 0; q < nm; ++q) {
+            std::vector<Acc> acc;
+            Step one = m; one.first = m.first + q; one.count = 1;
+            accesses(one, acc, true);
+            for (const Acc& a : acc) {
+                if (a.space != SP_GRAD || a.w) continue;
+                if (!covered(have, a.lo, a.hi)) { Acc z = a; z.w = true; z.space = m.stage; zero.push_back(z); have.push_back(a); }
+            }
+            int first = 0;
+            for (const Acc& a : acc) {
+                if (a.space != SP_GRAD || !a.w) continue;
+                if (!a.accum) { if (a.dense) have.push_back(a); continue; }      // plain store of a dense range
+                if (a.dense && !touches(have, a.lo, a.hi)) { first = 1; have.push_back(a); }
+                else if (!covered(have, a.lo, a.hi)) { Acc z = a; z.space = m.stage; zero.push_back(z); have.push_back(a); }
+            }
+            for (int k = 0; k < copies; ++k) {
+                const int idx = m.first + k * nm + q;
+                if (m.kind == K_GEMM) s_gemms[idx].out.first = first;
+                else if (m.kind == K_SEGRED) s_segreds[idx].first = first;
+                else if (m.kind == K_COMB_B) s_combines[idx].first = first;
+                else if (m.kind == K_ROW_B) s_rowlins[idx].first = first;
+            }
+        }
+    }
+}
+
 void mst_plan::schedule() {
     // Two GEMM tilings, both on v_mfma_f32_32x32x2_f32: few clips per launch are latency-bound and want many small
     // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about six clips per launch on
@@ -1022,6 +1097,18 @@ void mst_plan::schedule() {
     schedule_pass(bwd, sched[1], false);
     schedule_pass(fwd, sched_all[0], true);
     schedule_pass(bwd, sched_all[1], true);
+    std::vector<Acc> zs, za;
+    first_writers(sched[1], 0, true, zs);
+    first_writers(sched_all[1], 0, false, za);
+    // zero lists -> chunks of <= 16 K floats (one workgroup each); Acc.space carries the stage of the step that needs it
+    auto chunks = [&](const std::vector<Acc>& z, int stage_mask, std::vector<ZeroChunk>& out) {
+        for (const Acc& a : z) {
+            if (!(a.space & stage_mask)) continue;
+            for (int64_t at = a.lo; at < a.hi; at += 16384) out.push_back(ZeroChunk{at, (int32_t)std::min<int64_t>(16384, a.hi - at), 0});
+        }
+    };
+    for (int st = 0; st < 3; ++st) chunks(zs, 1 << st, zero_stage[st]);
+    chunks(za, MST_STAGE_ALL, zero_all);
 }
 
 template <class D>
@@ -1040,6 +1127,8 @@ int mst_plan::upload() {
     s_gemm_starts.resize(s_gemms.size());
     for (size_t i = 0; i < s_gemms.size(); ++i) s_gemm_starts[i] = s_gemms[i].blk_begin;
     e |= up(s_gemm_starts, &d_gemm_starts);
+    for (int st = 0; st < 3; ++st) e |= up(zero_stage[st], &d_zero_stage[st]);
+    e |= up(zero_all, &d_zero_all);
     for (int s = 0; s < 3; ++s) {
         for (auto& ent : slabs[s]) { ent.reps = K(); ent.rep_stride = tmp_top; }
         e |= up(slabs[s], &d_slabs[s]);
@@ -1080,7 +1169,8 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
-    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins);
+    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins); hipFree(p->d_zero_all);
+    for (int st = 0; st < 3; ++st) hipFree(p->d_zero_stage[st]);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
     delete p;
@@ -1168,26 +1258,13 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
 
 extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
     if (!p || !ws) return MST_ERR_ARG;
-    // the stage regions are allocated back to back: clear runs of selected stages with one memset each
+    // only the ranges the first-writer analysis could not prove written before they are read / accumulated into
     float* g = ws + (int64_t)p->K() * p->act_top;
-    for (int s = 0; s < 3;) {
-        if (!((mask >> s) & 1)) { ++s; continue; }
-        int e = s;
-        while (e + 1 < 3 && ((mask >> (e + 1)) & 1) && p->stage_begin[e + 1] == p->stage_end[e]) ++e;
-        const int64_t n = p->stage_end[e] - p->stage_begin[s];
-        if (n > 0) {
-            if (s == 0 && e == 2) {
-                // every stage of every clip: one memset from clip 0's first slot to the last clip's last slot (the input /
-                // loss slots of the gradient arena that this also covers are never read)
-                const int64_t span = (int64_t)(p->K() - 1) * p->act_top + n;
-                if (hipMemsetAsync(g + p->stage_begin[s], 0, span * sizeof(float), (hipStream_t)stream) != hipSuccess) return MST_ERR_LAUNCH;
-            } else {
-                for (int k = 0; k < p->K(); ++k)
-                    if (hipMemsetAsync(g + (int64_t)k * p->act_top + p->stage_begin[s], 0, n * sizeof(float), (hipStream_t)stream) != hipSuccess)
-                        return MST_ERR_LAUNCH;
-            }
-        }
-        s = e + 1;
+    if ((mask & MST_STAGE_ALL) == MST_STAGE_ALL)
+        return launch_zero(p->d_zero_all, (int)p->zero_all.size(), p->K(), g, p->act_top, (hipStream_t)stream) ? MST_ERR_LAUNCH : MST_OK;
+    for (int s = 0; s < 3; ++s) {
+        if (!((mask >> s) & 1)) continue;
+        if (launch_zero(p->d_zero_stage[s], (int)p->zero_stage[s].size(), p->K(), g, p->act_top, (hipStream_t)stream)) return MST_ERR_LAUNCH;
     }
     return MST_OK;
 }
@@ -1309,6 +1386,14 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
     }
     }
     *flops = f; *bytes = b;
+}
+
+extern "C" int64_t mst_plan_zero_floats(const mst_plan* p, int32_t mask) {
+    if (!p) return MST_ERR_ARG;
+    int64_t n = 0;
+    if ((mask & MST_STAGE_ALL) == MST_STAGE_ALL) { for (auto& c : p->zero_all) n += c.len; return n; }
+    for (int s = 0; s < 3; ++s) if ((mask >> s) & 1) for (auto& c : p->zero_stage[s]) n += c.len;
+    return n;
 }
 
 extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t backward) {

@@ -69,6 +69,7 @@ _SIGS = {
     'mst_forward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     'mst_backward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     'mst_zero_grads': (C.c_int32, [_P, C.c_int32, _P, _P]),
+    'mst_plan_zero_floats': (C.c_int64, [_P, C.c_int32]),
     'mst_loss_scratch_floats': (C.c_int64, []),
     'mst_total_loss_fwd': (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P,
                                        C.c_int32, _P, _P, _P, _P]),

@@ -15,6 +15,14 @@ FULL = dict(beat=64, bar=128, nrf=8, style=256, melody=8, rhythm=32)
 TOL = 1e-4          # rel-L2 tolerance of north_star ("within 1e-4 rel-L2 of the CPU reference")
 
 
+def poison(plan):
+    """NaN-fill the gradient and scratch arenas of the plan's workspace: a backward pass must write every gradient /
+    scratch element before it reads or accumulates into it (mst_zero_grads clears only what the first-writer analysis
+    could not prove written), so nothing of the poison may reach a result."""
+    goff = plan.clips * plan.clip_stride
+    plan.ws[goff:].fill_(float('nan'))
+
+
 def set_clip(plan, clip):
     plan.set_inputs(mode=clip['mode'], bpm=clip['bpm'], instr=clip['instruments_features'],
                     used=clip['used_instruments'], bpm_target=float(clip['bpm_int']))
@@ -38,6 +46,7 @@ def golden_small(native, device, name):
     gparams = torch.zeros_like(params)
     losses = torch.zeros(nat.N_LOSSES, device=device)
     xp, xu = dev_clip(clip, device)
+    poison(plan)
     plan.train_iteration(params, gparams, xp, xu, losses)
     checks = [('pitched_beats', 'mid/pitched_channels_encoder/0'), ('pitched_bars', 'mid/pitched_channels_encoder/1'),
               ('pitched_rhythm', 'mid/pitched_rhythm_encoder/0'), ('style', 'mid/style_encoder/0'),
@@ -108,6 +117,7 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
     gparams = torch.zeros_like(params)
     losses = torch.zeros(nat.N_LOSSES, device=device)
     xp, xu = dev_clip(clip, device)
+    poison(plan)
     plan.train_iteration(params, gparams, xp, xu, losses)
     out = dict(style=mids['style'], melody=mids['melody'], rhythm=mids['rhythm'], pitched_pred=xp_ref,
                instruments_pred=info[0], mode_pred=info[1], bpm_pred=info[2])
@@ -134,6 +144,7 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
     assert worst < 2e-3, ('worst per-tensor gradient', worst)
     if check_bitwise:   # fixed summation order everywhere: a second run must be bit-identical
         g2 = torch.zeros_like(params)
+        poison(plan)
         plan.train_iteration(params, g2, xp, xu, losses)
         assert torch.equal(g2, gparams)
     return e, worst
@@ -161,6 +172,7 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     xu = torch.cat([c['unpitched'] for c in clips]).contiguous().to(device) if unp else None
     gK = torch.zeros_like(params)
     lossesK = torch.zeros(K, nat.N_LOSSES, device=device)
+    poison(planK)
     planK.train_iteration(params, gK, xp, xu, lossesK)
     # (b) one-clip plan, K sequential iterations
     g1 = torch.zeros_like(params)
@@ -169,6 +181,7 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     for k, clip in enumerate(clips):
         set_clip(plan1, clip)
         a, b = dev_clip(clip, device)
+        poison(plan1)
         plan1.train_iteration(params, g1, a, b, losses1)
         for name in names:
             assert torch.equal(planK.view(name, clip=k), plan1.view(name)), (name, k)
