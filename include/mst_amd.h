@@ -76,7 +76,9 @@ typedef struct {
                                  * split-K tiles); 32 / 64 = force that tiling (experiments, parity tests) */
     int32_t no_merge;           /* 1 = one launch per scheduled member (profiling aid); 0 = merge a dependency level's
                                  * launches of one kernel */
-    int32_t reserved[6];        /* must be 0 */
+    int32_t gemm_run;           /* 64x64 tiling: output tiles one workgroup walks back to back; 0 = choose (1..8, keeping >= ~4096
+                                 * workgroups per launch) */
+    int32_t reserved[5];        /* must be 0 */
 } mst_plan_options;
 mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
 mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);

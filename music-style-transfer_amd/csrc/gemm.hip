@@ -361,31 +361,245 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
     }
 }
 
-__global__ __launch_bounds__(MF_THREADS) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
-    __shared__ float smem[2 * MF_KD * (MF_BM + GEMM_PAD)];
+// ---- lean loader for the dense operands of the throughput flavour --------------------------------
+// PMC on the generic body above (64 clips per launch): 17.7 VALU instructions per MFMA — the per-element index / predicate
+// arithmetic of the accessor loaders, re-derived every k-tile, kept the vector ALU busier than the matrix cores (37 % MFMA
+// busy).  Every operand of the Linear GEMMs (forward, input gradient, weight gradient, recurrent-weight gradient) is a
+// strided 2-D view with ONE unit-stride direction, so here a lane owns two groups of 4 consecutive elements along that
+// direction whose offsets are computed once; the k loop adds a scalar per tile and issues one 16-byte load per group
+// (two for an activation-gradient operand: dY and Y).  Only groups on an edge (M / N / k1 not a multiple of 4, the
+// bias-gradient ones column) take the predicated per-element path.
+// A workgroup owns a RUN of consecutive output tiles of one member (GemmDesc.run, same k-split) and walks them as one
+// flat sequence of (tile, k-tile) steps: the loads of the next step — also across a tile boundary — are issued before the
+// current step's MFMAs, so the descriptor fetch / first-load latency is paid once per run instead of once per tile (the
+// model's reductions are short: K = 64..135 is 2-5 k-tiles, and a one-tile workgroup spent most of its life waiting).
+// One barrier per k-tile: the LDS tiles are double-buffered (a wave that passed barrier t + 1 has finished reading buffer
+// t & 1), and the barrier is LDS-only (MST_LDS_BARRIER), so the next step's global loads stay in flight across it —
+// __syncthreads() would drain them (vmcnt(0)) before every barrier.
+typedef float (*mf_tile_t)[MF_BM + GEMM_PAD];
+template <int AK, int OK, int AKF, int BKF>
+__device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b, const int t_begin, const int t_end, const int split,
+                                               float* smem) {
+    static_assert(AK == OPK_DENSE || AK == OPK_ACTGRAD, "dense operands only");
+    const int tid = threadIdx.x;
+    const int M = d.M, N = d.N;
+    const int tiles_n = (N + MF_BN - 1) / MF_BN;
+    int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
+    kchunk = (kchunk + MF_KD - 1) / MF_KD * MF_KD;
+    const int k0 = split * kchunk;
+    const int k1 = min(d.K, k0 + kchunk);
+    if (k0 >= k1 || t_begin >= t_end) return;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int wm = wv >> 1, wn = wv & 1;
+    const gcptr baseA = (gcptr)(b.p[d.A.space] + d.A.off);
+    const gcptr baseY = AK == OPK_ACTGRAD ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
+    const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
+    // element strides: A(m, k) = baseA[m * sAm + k * sAk], B(k, n) = baseB[k * sBk + n * sBn]; the *KF direction is unit stride
+    const int sAm = AK == OPK_DENSE ? (int)d.A.si : (d.A.transposed ? 1 : d.A.ld);
+    const int sAk = AK == OPK_DENSE ? (int)d.A.sj : (d.A.transposed ? d.A.ld : 1);
+    const int sBk = (int)d.B.si, sBn = (int)d.B.sj;
+    const int a_act = AK == OPK_ACTGRAD ? d.A.act : ACT_NONE;
+    const int a_tr = d.A.transposed;
+    const int b_ones = d.B.ones_at;
+    // group geometry.  KF = 1 (k is unit stride): row = (tid >> 3) + 32 g, k = 4 (tid & 7) + j.
+    //                  KF = 0 (row is unit stride): k = (tid >> 4) + 16 g, row = 4 (tid & 15) + j.
+    const int arow0 = AKF ? (tid >> 3) : 4 * (tid & 15), akl0 = AKF ? 4 * (tid & 7) : (tid >> 4);
+    const int brow0 = BKF ? (tid >> 3) : 4 * (tid & 15), bkl0 = BKF ? 4 * (tid & 7) : (tid >> 4);
+    // per-tile constants of this lane's groups: element offset of the first element at k = 0, and whether the group's rows
+    // are all inside the matrix (KF = 0) / its row is (KF = 1)
+    struct Geo { int tm, tn, aoff[2], boff[2]; bool avec[2], bvec[2]; };
+    auto geo_of = [&](const int t, Geo& q) {
+        q.tm = t / tiles_n; q.tn = t - q.tm * tiles_n;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int mr = q.tm * MF_BM + arow0 + (AKF ? 32 * g : 0);
+            q.avec[g] = AKF ? mr < M : mr + 3 < M;
+            q.aoff[g] = min(mr, M - 1) * sAm + (AKF ? akl0 : (akl0 + 16 * g) * sAk);
+            const int nr = q.tn * MF_BN + brow0 + (BKF ? 32 * g : 0);
+            q.bvec[g] = BKF ? nr < N : (nr + 3 < N) & !((b_ones >= nr) & (b_ones <= nr + 3));
+            q.boff[g] = min(nr, N - 1) * sBn + (BKF ? bkl0 : (bkl0 + 16 * g) * sBk);
+        }
+    };
+    mf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float va[8], vy[8], vb[8];
+    auto issue = [&](const Geo& q, const int kt) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            // ---- A
+            if (AKF) {
+                const int kk = kt + akl0;                              // this group's first k
+                const int o = q.aoff[g] + kt;
+                if (q.avec[g] & (kk + 3 < k1)) {
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (unsigned)o);
+                    va[4 * g] = t[0]; va[4 * g + 1] = t[1]; va[4 * g + 2] = t[2]; va[4 * g + 3] = t[3];
+                    if constexpr (AK == OPK_ACTGRAD) {
+                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseY + (unsigned)o);
+                        vy[4 * g] = u[0]; vy[4 * g + 1] = u[1]; vy[4 * g + 2] = u[2]; vy[4 * g + 3] = u[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = q.avec[g] & (kk + j < k1);
+                        va[4 * g + j] = ok ? baseA[(unsigned)(ok ? o + j : 0)] : 0.f;
+                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? baseY[(unsigned)(ok ? o + j : 0)] : 0.f;
+                    }
+                }
+            } else {
+                const int kk = kt + akl0 + 16 * g;
+                const bool kok = kk < k1;
+                const int o = q.aoff[g] + kt * sAk;
+                if (q.avec[g] & kok) {
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (unsigned)o);
+                    va[4 * g] = t[0]; va[4 * g + 1] = t[1]; va[4 * g + 2] = t[2]; va[4 * g + 3] = t[3];
+                    if constexpr (AK == OPK_ACTGRAD) {
+                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseY + (unsigned)o);
+                        vy[4 * g] = u[0]; vy[4 * g + 1] = u[1]; vy[4 * g + 2] = u[2]; vy[4 * g + 3] = u[3];
+                    }
+                } else {
+                    const int mr = q.tm * MF_BM + arow0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = kok & (mr + j < M);
+                        const int oj = ok ? (mr + j) * sAm + kk * sAk : 0;
+                        va[4 * g + j] = ok ? baseA[(unsigned)oj] : 0.f;
+                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? baseY[(unsigned)oj] : 0.f;
+                    }
+                }
+            }
+            // ---- B
+            if (BKF) {
+                const int kk = kt + bkl0;
+                const int o = q.boff[g] + kt;
+                if (q.bvec[g] & (kk + 3 < k1)) {
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (unsigned)o);
+                    vb[4 * g] = t[0]; vb[4 * g + 1] = t[1]; vb[4 * g + 2] = t[2]; vb[4 * g + 3] = t[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = q.bvec[g] & (kk + j < k1);
+                        vb[4 * g + j] = ok ? baseB[(unsigned)(ok ? o + j : 0)] : 0.f;
+                    }
+                }
+            } else {
+                const int kk = kt + bkl0 + 16 * g;
+                const bool kok = kk < k1;
+                const int o = q.boff[g] + kt * sBk;
+                if (q.bvec[g] & kok) {
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (unsigned)o);
+                    vb[4 * g] = t[0]; vb[4 * g + 1] = t[1]; vb[4 * g + 2] = t[2]; vb[4 * g + 3] = t[3];
+                } else {
+                    const int nr = q.tn * MF_BN + brow0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = kok & (nr + j < N);
+                        const bool one = ok & (nr + j == b_ones);
+                        const float w = baseB[(unsigned)((ok & !one) ? kk * sBk + (nr + j) * sBn : 0)];
+                        vb[4 * g + j] = one ? 1.f : (ok ? w : 0.f);
+                    }
+                }
+            }
+        }
+    };
+    constexpr int TILE_F = MF_KD * (MF_BM + GEMM_PAD);
+    float* cbase = b.p[d.out.space] + d.out.off;
+    const float* bias = d.out.bias_space >= 0 ? b.p[d.out.bias_space] + d.out.bias_off : nullptr;
+    Geo gl;                                  // geometry of the step whose operands sit in va / vy / vb
+    geo_of(t_begin, gl);
+    issue(gl, k0);
+    int t = t_begin, kt = k0, buf = 0;
+    while (true) {                           // workgroup-uniform
+        const mf_tile_t As = reinterpret_cast<mf_tile_t>(smem + buf * 2 * TILE_F);
+        const mf_tile_t Bs = reinterpret_cast<mf_tile_t>(smem + buf * 2 * TILE_F + TILE_F);
+        const int tm = gl.tm, tn = gl.tn;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ar = AKF ? arow0 + 32 * g : arow0 + j, ak = AKF ? akl0 + j : akl0 + 16 * g;
+                float v = va[4 * g + j];
+                if constexpr (AK == OPK_ACTGRAD) {
+                    const int col = a_tr ? tm * MF_BM + ar : kt + ak;
+                    v *= act_bwd(a_act, vy[4 * g + j], col);
+                }
+                As[ak][ar] = v;
+                const int br = BKF ? brow0 + 32 * g : brow0 + j, bk = BKF ? bkl0 + j : bkl0 + 16 * g;
+                Bs[bk][br] = vb[4 * g + j];
+            }
+        }
+        MST_LDS_BARRIER();
+        // next step: the next k-tile of this tile, or the first k-tile of the next tile of the run
+        const bool last_k = kt + MF_KD >= k1;
+        const int nt = last_k ? t + 1 : t, nkt = last_k ? k0 : kt + MF_KD;
+        const bool more = nt < t_end;
+        if (more) {
+            if (last_k) geo_of(nt, gl);
+            issue(gl, nkt);                  // flies under this step's MFMAs, the epilogue and the barrier
+        }
+#pragma unroll
+        for (int kk = 0; kk < MF_KD / 2; ++kk) {
+            const int k = kk * 2 + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][wm * 32 + (lane & 31)], Bs[k][wn * 32 + (lane & 31)], acc, 0, 0, 0);
+        }
+        if (last_k) {
+            const int n = tn * MF_BN + wn * 32 + (lane & 31);
+            if ((tm * MF_BM + wm * 32 < M) & (tn * MF_BN + wn * 32 < N)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tm * MF_BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < M && n < N) store_out<OK>(d, cbase, bias, m, n, split, acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        if (!more) break;
+        t = nt; kt = nkt; buf ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(MF_THREADS, 4) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
+    __shared__ float smem[2 * 2 * MF_KD * (MF_BM + GEMM_PAD)];        // two (A | B) tile pairs: the lean body double-buffers
     float (*As)[MF_BM + GEMM_PAD] = reinterpret_cast<float (*)[MF_BM + GEMM_PAD]>(smem);
     float (*Bs)[MF_BN + GEMM_PAD] = reinterpret_cast<float (*)[MF_BN + GEMM_PAD]>(smem + MF_KD * (MF_BM + GEMM_PAD));
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
-    int y = 0;
-    while (y + 1 < count && lb >= starts[y + 1]) ++y;          // starts[]: one cache line, not one descriptor per probe
-    const GemmDesc d = descs[clip * count + y];
+    // member y owns the workgroups [starts[y], starts[y + 1]) of a clip's range: binary search (a merged launch of the
+    // backward pass has hundreds of members; the linear probe was a chain of that many dependent scalar loads)
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lb >= starts[mid]) lo = mid; else hi = mid - 1;
+    }
+    const GemmDesc d = descs[clip * count + lo];
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + MF_BM - 1) / MF_BM) * ((d.N + MF_BN - 1) / MF_BN);
-    const int tile = local % ntile, split = local / ntile;
+    const int run = d.run > 0 ? d.run : 1, nruns = (ntile + run - 1) / run;
+    const int split = local / nruns, t_begin = (local - split * nruns) * run, t_end = min(ntile, t_begin + run);
     switch (d.variant) {
-    case GV_LIN_FWD: gemm_mfma_body<OPK_DENSE, OPK_DENSE, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_FWD_PERM: gemm_mfma_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DW: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DW_PERM: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_PERMW_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
-    case GV_LIN_DA: gemm_mfma_body<OPK_ACTGRAD, OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, tile, split, As, Bs); break;
-    case GV_CONV_FWD: gemm_mfma_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs); break;
-    case GV_CONV_DW: gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs); break;
-    case GV_HH_DW: gemm_mfma_body<OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0>(d, b, tile, split, As, Bs); break;
-    default: break;
+    case GV_LIN_FWD: gemm_fast_body<OPK_DENSE, OUT_STORE, 1, 1>(d, b, t_begin, t_end, split, smem); break;
+    case GV_LIN_DW: gemm_fast_body<OPK_ACTGRAD, OUT_SLAB, 0, 0>(d, b, t_begin, t_end, split, smem); break;
+    case GV_LIN_DW_PERM: gemm_fast_body<OPK_ACTGRAD, OUT_PERMW_SLAB, 0, 0>(d, b, t_begin, t_end, split, smem); break;
+    case GV_LIN_DA: gemm_fast_body<OPK_ACTGRAD, OUT_ACCUM, 1, 0>(d, b, t_begin, t_end, split, smem); break;
+    case GV_HH_DW: gemm_fast_body<OPK_DENSE, OUT_SLAB, 0, 0>(d, b, t_begin, t_end, split, smem); break;
+    default:
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            if (tile > t_begin) __syncthreads();
+            if (d.variant == GV_LIN_FWD_PERM) gemm_mfma_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs);
+            else if (d.variant == GV_CONV_FWD) gemm_mfma_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs);
+            else if (d.variant == GV_CONV_DW) gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs);
+        }
+        break;
     }
 }
 
 int gemm_tile_edge(int mfma) { return mfma ? MF_BM : GEMM_BM; }
+int gemm_blocks(const GemmDesc& g, int mfma) {
+    const int edge = gemm_tile_edge(mfma);
+    const int ntile = ((g.M + edge - 1) / edge) * ((g.N + edge - 1) / edge);
+    const int run = (mfma && g.run > 1) ? g.run : 1;
+    return ((ntile + run - 1) / run) * g.ksplit;
+}
 
 // One kernel for every GEMM of the model: blockIdx.y picks the descriptor, the descriptor's
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
@@ -399,9 +613,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __re
     float (*Bs)[GEMM_BN + GEMM_PAD] = reinterpret_cast<float (*)[GEMM_BN + GEMM_PAD]>(smem + TILE_F);
     // flat 1-D grid: clip-major; inside a clip's block range member y owns [blk_begin, blk_begin + tiles * ksplit)
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
-    int y = 0;
-    while (y + 1 < count && lb >= starts[y + 1]) ++y;          // starts[]: one cache line, not one descriptor per probe
-    const GemmDesc d = descs[clip * count + y];      // by value (scalar loads once): a reference would be re-read after every barrier
+    int lo = 0, hi = count - 1;                      // member y owns [starts[y], starts[y + 1]): binary search
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lb >= starts[mid]) lo = mid; else hi = mid - 1;
+    }
+    const GemmDesc d = descs[clip * count + lo];     // by value (scalar loads once): a reference would be re-read after every barrier
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
     const int tile = local % ntile, split = local / ntile;

@@ -95,6 +95,7 @@ struct GemmDesc {
     int32_t variant;     // GV_* instantiation (filled by the plan from the operand kinds)
     int32_t blk_begin;   // first workgroup of this member inside its (merged) launch
     int32_t kdsel;       // k-tile depth: 0 -> 32, 1 -> 64, 2 -> 128
+    int32_t run;         // 64x64 tiling: consecutive output tiles one workgroup walks (same k-split); 0 / 1 = one tile
     Operand A, B;
     OutSpec out;
 };
@@ -159,7 +160,7 @@ struct NotesDesc {
     int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)
     int64_t out_off;             // ME: melody (Q,F,56,W), the channels already combined; PSA: (P,F,56,5)
     int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;
-    int64_t slab_off; int32_t slab_stride; int32_t nblk;    // one slab row per WAVE: 4 * nblk rows
+    int64_t slab_off; int32_t slab_stride; int32_t nblk;    // one slab row per workgroup
     // ME only: the channel combine (style/model.py:296,796-815) is fused in.  nwc waves per channel leave partial sums:
     int32_t nwc;                 // <= 64
     int64_t part_off;            // [SP_TMP] forward: C*nwc partial sums of squares; backward: C*nwc partial a_c, then nwc partial b
@@ -210,6 +211,7 @@ int gemm_variant(const GemmDesc& g);
 // dev_starts: the members' blk_begin values as a dense int array (index = position of the clip-0 descriptor)
 int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
 int gemm_tile_edge(int mfma);
+int gemm_blocks(const GemmDesc& g, int mfma);       // workgroups of one member (tiles / run x k-splits)
 int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip, int clips, int stage2_blocks, Bases b, hipStream_t s);
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);

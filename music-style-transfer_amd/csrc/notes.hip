@@ -319,18 +319,25 @@ __global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* _
         }
         __syncthreads();
     }
-    // one slab row per wave: channels_linear.{weight,bias}, linear.{weight,bias} in parameter order
-    float* slab = b.p[SP_TMP] + d.slab_off + (int64_t)(blockIdx.x * 4 + wv) * d.slab_stride;
+    // one slab row per workgroup: channels_linear.{weight,bias}, linear.{weight,bias} in parameter order; the four waves'
+    // partial sums meet in wave order
+    constexpr int NWT = R_BL + W;
+    static_assert(NWT <= 256, "slab row wider than the workgroup");
+    float* wsum = &tr[0][0][0];                            // the staging rows are free now: 4 x NWT floats
+    __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int row = 4 * kh + rr;
         if (row < W) {
-            if (r < KL) slab[R_WL + row * KL + r] = accW[rr]; else if (r == KL) slab[R_BL + row] = accW[rr];
+            if (r < KL) wsum[wv * NWT + R_WL + row * KL + r] = accW[rr]; else if (r == KL) wsum[wv * NWT + R_BL + row] = accW[rr];
         }
         if (row < CW) {
-            if (r < NPF) slab[R_WC + row * NPF + r] = accC[rr]; else if (r == NPF) slab[R_BC + row] = accC[rr];
+            if (r < NPF) wsum[wv * NWT + R_WC + row * NPF + r] = accC[rr]; else if (r == NPF) wsum[wv * NWT + R_BC + row] = accC[rr];
         }
     }
+    __syncthreads();
+    if (tid < NWT)
+        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = (wsum[tid] + wsum[NWT + tid]) + (wsum[2 * NWT + tid] + wsum[3 * NWT + tid]);
 }
 
 // ============================================================================ PitchedStyleApplier
@@ -572,16 +579,18 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
         }
         cur = nxt; qf = nqf; c0 = nc0; have = nhave;
     }
-    // ---- one slab row per wave: linear.weight (5 x KL) then linear.bias (5); partial sums meet in a fixed order
-    float* slab = b.p[SP_TMP] + d.slab_off + (int64_t)(blockIdx.x * 4 + wv) * d.slab_stride;
+    // ---- one slab row per workgroup: linear.weight (5 x KL) then linear.bias (5); partial sums meet in a fixed order
+    constexpr int NWT = NPF * KL + NPF;
+    static_assert(NWT <= 256 && 4 * NWT <= 4 * 2 * NPN * 8, "slab row wider than the workgroup / the staging it reuses");
+    float* wsum = &dz_s[0][0][0][0] + wv * NWT;           // dz staging is free now
     float (*red)[64] = red_s[wv];
-    MST_WAVE_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPF; ++i) red[i][lane] = dwj[i];
     MST_WAVE_SYNC();
     if (lane < PSA_HW) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) slab[i * KL + lane] = red[i][lane] + red[i][lane + 32];
+        for (int i = 0; i < NPF; ++i) wsum[i * KL + lane] = red[i][lane] + red[i][lane + 32];
     }
     MST_WAVE_SYNC();
 #pragma unroll
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
             float a = red[i][lane];
 #pragma unroll
             for (int gq = 1; gq < NG; ++gq) a += red[i][lane + gq * ML];
-            slab[i * KL + PSA_HW + lane] = a;
+            wsum[i * KL + PSA_HW + lane] = a;
         }
     }
     MST_WAVE_SYNC();
@@ -604,8 +613,12 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
         float a = red[lane][0];
 #pragma unroll
         for (int gq = 1; gq < NG; ++gq) a += red[lane][gq * ML];
-        slab[NPF * KL + lane] = a;
+        wsum[NPF * KL + lane] = a;
     }
+    __syncthreads();
+    const float* w0 = &dz_s[0][0][0][0];
+    if (tid < NWT)
+        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = (w0[tid] + w0[NWT + tid]) + (w0[2 * NWT + tid] + w0[3 * NWT + tid]);
 }
 
 // ============================================================================ dispatch

@@ -664,7 +664,7 @@ void mst_plan::build() {
         // wave leaves one slab row for the deferred reduction
         const int me_blk = K() == 1 ? 256 : (2048 / K() < 4 ? 4 : (2048 / K() > 256 ? 256 : 2048 / K()));
         const int want = (P_ + 1) / 2;
-        n.nblk = want < me_blk ? want : me_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk * 4);
+        n.nblk = want < me_blk ? want : me_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = E;
         op.fwd.push_back(Step{K_ME_SQ, (int)notes.size(), 1, 0, 0});
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
@@ -672,7 +672,7 @@ void mst_plan::build() {
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
         notes.push_back(n); ops.push_back(op);
         // channels_linear.{weight,bias}, linear.{weight,bias} are contiguous in the flat buffer
-        slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk * 4});
+        slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk});
     }
     stage_end[0] = act_top;
 
@@ -720,12 +720,12 @@ void mst_plan::build() {
         // forward: a workgroup per qf up to the cap.  backward: a wave per qf, four per workgroup, one slab row per wave
         const int psa_blk = K() == 1 ? 512 : (4096 / K() < 8 ? 8 : (4096 / K() > 512 ? 512 : 4096 / K()));
         const int want = (qf + 3) / 4;
-        n.nblk = want < psa_blk ? want : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk * 4);
+        n.nblk = want < psa_blk ? want : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
         notes.push_back(n); ops.push_back(op);
-        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk * 4});
+        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk});
     }
     if (U) {
         m = "unpitched_style_applier";
@@ -898,7 +898,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
                 acc_add(v, SP_GRAD, n.g_out_off, mel, false);
                 acc_add(v, SP_GRAD, n.g_oct_off, rows * NOCT * n.W, true);
                 acc_add(v, SP_GRAD, n.g_deg_off, rows * NDEG * n.W, true);
-                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk * 4, true);
+                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
             }
             break;
         }
@@ -918,7 +918,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
                 acc_add(v, SP_GRAD, n.g_oct_off, rows * ow, true);
                 acc_add(v, SP_GRAD, n.g_deg_off, rows * dw, true);
                 if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
-                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk * 4, true);
+                acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
             }
             break;
         }
@@ -985,6 +985,10 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                         GemmDesc g = reloc(gemms[idx], k); g.variant = gemm_variant(g);
                         const int kr = (g.K + g.ksplit - 1) / g.ksplit;
                         g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2);
+                        // tiles per workgroup (64x64 tiling): measured on MI355X at 64 clips per launch, runs of 2 / 4 / 8 tiles
+                        // lost 7 / 22 / 33 % against one tile per workgroup (fewer, longer workgroups: worse balance over the
+                        // 256 CUs than the saved per-workgroup latency buys), so the default stays 1; the option remains for experiments
+                        g.run = (mfma && opt.gemm_run > 1) ? opt.gemm_run : 1;
                         if (g.variant < 0) err = MST_ERR_UNSUPPORTED;
                         s_gemms.push_back(g);
                     }
@@ -1003,8 +1007,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 for (int q = 0; q < nm; ++q) {
                     const GemmDesc& g0 = s_gemms[m.first + q];
                     for (int k = 0; k < copies; ++k) s_gemms[m.first + k * nm + q].blk_begin = total;
-                    const int edge = gemm_tile_edge(mfma);
-                    total += ((g0.M + edge - 1) / edge) * ((g0.N + edge - 1) / edge) * g0.ksplit;
+                    total += gemm_blocks(g0, mfma);
                 }
                 m.a = total; m.b = nm;        // blocks per clip, members per clip
             }
@@ -1152,7 +1155,7 @@ extern "C" mst_plan* mst_plan_create(const mst_dims* d, int32_t* status) { retur
 extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status) {
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
-    if (opt && (opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64)) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && ((opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64) || opt->gemm_run < 0 || opt->gemm_run > 64)) { *status = MST_ERR_ARG; return nullptr; }
     mst_plan* p = new mst_plan();
     if (opt) p->opt = *opt;
     p->d = *d; p->z = mst_sizes(*d);

@@ -39,7 +39,7 @@ class Dims(C.Structure):
 
 
 class PlanOptions(C.Structure):
-    _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('reserved', C.c_int32 * 6)]
+    _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('reserved', C.c_int32 * 5)]
 
 
 def options_from_env():
@@ -48,7 +48,8 @@ def options_from_env():
     ge = os.environ.get('MST_GEMM')
     if ge not in (None, '', 'mfma', 'valu'):
         raise MstError(f'MST_GEMM={ge!r}: expected mfma or valu')
-    return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))))
+    return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))),
+                gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')))
 
 
 _P = C.c_void_p
@@ -158,11 +159,12 @@ class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
     WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
         env = options_from_env()
         opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
-                           no_merge=env['no_merge'] if no_merge is None else int(no_merge))
+                           no_merge=env['no_merge'] if no_merge is None else int(no_merge),
+                           gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run))
         st = C.c_int32()
         self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:

@@ -49,6 +49,13 @@ def test_batched_clips_on_the_mfma_gemm():
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4)
 
 
+def test_mfma_gemm_runs_of_several_tiles_per_workgroup():
+    # the 64x64 tiling walks a run of output tiles per workgroup (prefetching across tile boundaries); at test sizes the
+    # automatic choice is one tile, so force runs of 3 (tile counts that are not multiples of it included)
+    pc.oracle_case(sim_native(), 'cpu', pc.FULL, 2, 3, 2, True, density=0.03, gemm_tile=64, gemm_run=3)
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4, gemm_tile=64, gemm_run=2)
+
+
 def test_single_clip_on_the_mfma_gemm(monkeypatch):
     monkeypatch.setenv('MST_GEMM', 'mfma')
     pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True)
