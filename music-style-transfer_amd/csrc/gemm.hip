@@ -582,6 +582,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void gemm_mfma_kernel(const GemmDesc
     case GV_LIN_DW_PERM: gemm_fast_body<OPK_ACTGRAD, OUT_PERMW_SLAB, 0, 0>(d, b, t_begin, t_end, split, smem); break;
     case GV_LIN_DA: gemm_fast_body<OPK_ACTGRAD, OUT_ACCUM, 1, 0>(d, b, t_begin, t_end, split, smem); break;
     case GV_HH_DW: gemm_fast_body<OPK_DENSE, OUT_SLAB, 0, 0>(d, b, t_begin, t_end, split, smem); break;
+    case GV_LIN_DA_RAW: gemm_fast_body<OPK_DENSE, OUT_ACCUM, 1, 0>(d, b, t_begin, t_end, split, smem); break;
     default:
         for (int tile = t_begin; tile < t_end; ++tile) {
             if (tile > t_begin) __syncthreads();
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __re
         GEMM_CASE(GV_CONV_FWD, OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1)
         GEMM_CASE(GV_CONV_DW, OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0)
         GEMM_CASE(GV_HH_DW, OPK_DENSE, OPK_DENSE, OUT_SLAB, 0, 0)
+        GEMM_CASE(GV_LIN_DA_RAW, OPK_DENSE, OPK_DENSE, OUT_ACCUM, 1, 0)
     default: break;
     }
 #undef GEMM_CASE
@@ -650,6 +652,7 @@ int gemm_variant(const GemmDesc& g) {
     if (a == OPK_IM2COL && bk == OPK_PERMW && o == OUT_CONV) return GV_CONV_FWD;
     if (a == OPK_CONVGRAD && bk == OPK_IM2COL && o == OUT_PERMW_SLAB) return GV_CONV_DW;
     if (a == OPK_DENSE && bk == OPK_DENSE && o == OUT_SLAB) return GV_HH_DW;
+    if (a == OPK_DENSE && bk == OPK_DENSE && o == OUT_ACCUM) return GV_LIN_DA_RAW;
     return -1;
 }
 
@@ -803,7 +806,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
     }
     part[g][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (g == 0 && i < e.count) b.p[SP_GPAR][e.dst + i] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (g == 0 && i < e.count) {
+        const int64_t di = e.width > 0 ? (int64_t)(i / e.width) * e.dst_ld + i % e.width : i;      // block of a wider matrix
+        b.p[SP_GPAR][e.dst + di] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    }
 }
 
 __global__ __launch_bounds__(256) void zero_kernel(const ZeroChunk* __restrict__ ch, float* g, int64_t clip_stride) {

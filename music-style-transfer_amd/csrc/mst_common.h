@@ -154,12 +154,16 @@ struct CombineDesc {
 struct NotesDesc {
     int32_t C, Q;                // channels, R*T
     int32_t W, CW, ML;           // melody width, channels_linear width, melody_linear width
-    int64_t oct_off, deg_off;    // ME: (P, 8W),(P,7W);  PSA: (P*F, 240),(P*F, 210)
+    int64_t oct_off, deg_off;    // ME: (P, 8W),(P,7W);  PSA: unused (the octave / degree rows are rt + it, below)
+    // PSA: octave_linear / scale_degree_linear act on a broadcast-concat [style | rhythm(q,f) | instrument(c)], so their
+    // pre-activations decompose: z[c, qf] = rt[qf] + it[c] (it carries the style part and the bias).  [SP_WS]
+    int64_t rt_oct_off, rt_deg_off;      // (Q*F, 240), (Q*F, 210)
+    int64_t it_oct_off, it_deg_off;      // (C, 240), (C, 210)
     int64_t x_off; int32_t x_space;  // ME: pitched input
     int64_t ml_off;              // PSA: (Q*F*56, ML)
     int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)
     int64_t out_off;             // ME: melody (Q,F,56,W), the channels already combined; PSA: (P,F,56,5)
-    int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;
+    int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;   // PSA: g_oct / g_deg = gradient of the PRE-activations z, (P*F, 240 | 210)
     int64_t slab_off; int32_t slab_stride; int32_t nblk;    // one slab row per workgroup
     // ME only: the channel combine (style/model.py:296,796-815) is fused in.  nwc waves per channel leave partial sums:
     int32_t nwc;                 // <= 64
@@ -180,7 +184,9 @@ struct RowLinDesc {
 
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
-struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; };
+// width > 0: the entry is a (count / width) x width block of a wider parameter matrix: element i lands at
+// dst + (i / width) * dst_ld + i % width (column blocks of a Linear whose input is a broadcast-concat, plan.hip linear_part)
+struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; int32_t width, dst_ld; };
 struct SlabBlock { int32_t entry, start; };   // one workgroup's 64-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)
@@ -202,7 +208,7 @@ struct Sizes {
 Sizes mst_sizes(const mst_dims& d);
 
 // ---- launchers (each returns a hipError_t-style int; 0 = ok)
-enum { GV_LIN_FWD, GV_LIN_FWD_PERM, GV_LIN_DW, GV_LIN_DW_PERM, GV_LIN_DA, GV_CONV_FWD, GV_CONV_DW, GV_HH_DW };
+enum { GV_LIN_FWD, GV_LIN_FWD_PERM, GV_LIN_DW, GV_LIN_DW_PERM, GV_LIN_DA, GV_CONV_FWD, GV_CONV_DW, GV_HH_DW, GV_LIN_DA_RAW };
 int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipStream_t s);
 int gemm_variant(const GemmDesc& g);
 // descs = clips x members (clip-major); every clip's copy of a member has the same blk_begin inside the clip's block range

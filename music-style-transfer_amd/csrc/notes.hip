@@ -355,19 +355,28 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
     float* ws = b.p[SP_WS];
     const int QF = d.Q * NF;
     const int n = tid, o = n / NDEG, dg = n - o * NDEG;
-    // the octave | degree rows of the NEXT (qf, c) sit in 8 registers per lane while the current one is processed
+    // octave | degree rows: leaky(rt[qf] + it[c]) (the Linear over the broadcast-concat, decomposed: plan.hip).  The rt row of
+    // the qf and the it row of the NEXT channel sit in registers while the current (qf, c) is processed
     constexpr int NLO = NOCT * PSA_HW, NOD = (NOCT + NDEG) * PSA_HW, NPRE = (NOD + 63) / 64;
-    float od[NPRE];
-    auto fetch_od = [&](int64_t row) {
+    float rtv[NPRE], od[NPRE];
+    auto fetch_rt = [&](int64_t q_) {
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
             const int i = tid + 64 * q;
-            od[q] = i < NLO ? ws[d.oct_off + row * NLO + i] : (i < NOD ? ws[d.deg_off + row * (NOD - NLO) + (i - NLO)] : 0.f);
+            rtv[q] = i < NLO ? ws[d.rt_oct_off + q_ * NLO + i] : (i < NOD ? ws[d.rt_deg_off + q_ * (NOD - NLO) + (i - NLO)] : 0.f);
         }
     };
-    if ((int)blockIdx.x < QF) fetch_od((int64_t)blockIdx.x);
+    auto fetch_od = [&](int c_) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int i = tid + 64 * q;
+            od[q] = i < NLO ? ws[d.it_oct_off + (int64_t)c_ * NLO + i] : (i < NOD ? ws[d.it_deg_off + (int64_t)c_ * (NOD - NLO) + (i - NLO)] : 0.f);
+        }
+    };
+    fetch_od(0);
     for (int qf = blockIdx.x; qf < QF; qf += gridDim.x) {
         __syncthreads();
+        fetch_rt(qf);
         float zm[NPF];
 #pragma unroll
         for (int i = 0; i < NPF; ++i) zm[i] = 0.f;
@@ -387,11 +396,11 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 const int i = tid + 64 * q;
-                if (i < NLO) lo_s[i] = od[q]; else if (i < NOD) ld_s[i - NLO] = od[q];
+                const float zv = lrelu(rtv[q] + od[q]);
+                if (i < NLO) lo_s[i] = zv; else if (i < NOD) ld_s[i - NLO] = zv;
             }
             __syncthreads();
-            if (c + 1 < d.C) fetch_od((int64_t)(c + 1) * QF + qf);
-            else if (qf + (int)gridDim.x < QF) fetch_od((int64_t)(qf + gridDim.x));
+            fetch_od(c + 1 < d.C ? c + 1 : 0);
             if (n < NPN) {
                 float z[NPF];
 #pragma unroll
@@ -470,14 +479,17 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
     }
     // Everything a row pair reads from global memory, fetched ONE PAIR AHEAD of its use (two waves per SIMD cannot hide a
     // dependent load behind another wave's work): degree rows, octave rows, predictions and their gradients.
+    // (octave / degree rows = leaky(rt[qf] + it[c]): the Linear over the broadcast-concat, decomposed — plan.hip)
     struct PairIn { float ld[NDEG], lo[NOCT], y[NSLOT], dy[NSLOT]; };
     auto fetch = [&](int qf, int c0, PairIn& r) {
         const int c = c0 + half;
-        const int64_t row = (int64_t)(c < d.C ? c : d.C - 1) * QF + qf;
+        const int64_t cc_ = c < d.C ? c : d.C - 1;
 #pragma unroll
-        for (int q = 0; q < NDEG; ++q) r.ld[q] = ws[d.deg_off + row * NLD + q * PSA_HW + j];
+        for (int q = 0; q < NDEG; ++q)
+            r.ld[q] = lrelu(ws[d.rt_deg_off + (int64_t)qf * NLD + q * PSA_HW + j] + ws[d.it_deg_off + cc_ * NLD + q * PSA_HW + j]);
 #pragma unroll
-        for (int o = 0; o < NOCT; ++o) r.lo[o] = ws[d.oct_off + row * NLO + o * PSA_HW + j];
+        for (int o = 0; o < NOCT; ++o)
+            r.lo[o] = lrelu(ws[d.rt_oct_off + (int64_t)qf * NLO + o * PSA_HW + j] + ws[d.it_oct_off + cc_ * NLO + o * PSA_HW + j]);
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             const int cc = c0 + (e_rowb[q] ? 1 : 0);
@@ -542,11 +554,12 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
                 const float g = dh * slope;
                 dlo += g; dld[dg] += g;
             }
-            if (jvalid && rvalid) glop[o * PSA_HW] = dlo;      // sole writer of this row's octave / degree gradients
+            // gradient of the PRE-activation (leaky' from the activation's sign); sole writer of this row
+            if (jvalid && rvalid) glop[o * PSA_HW] = dlo * dlrelu(lo);
         }
         if (jvalid && rvalid) {
 #pragma unroll
-            for (int q = 0; q < NDEG; ++q) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dld[q];
+            for (int q = 0; q < NDEG; ++q) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dld[q] * dlrelu(cur.ld[q]);
         }
         if (nc0 == 0) {
             // ---- last pair of this qf: the melody-linear columns from the channel sums

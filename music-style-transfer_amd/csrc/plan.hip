@@ -249,6 +249,7 @@ struct mst_plan {
             if (o->kind == OPK_ACTGRAD || o->kind == OPK_CONVGRAD) o->off2 += shift(o->space2, k);
         }
         g.out.off += shift(g.out.space, k);
+        if (g.out.bias_space >= 0) g.out.bias_off += shift(g.out.bias_space, k);      // 0 for a parameter bias
         return g;
     }
     GatherDesc reloc(GatherDesc g, int k) const {
@@ -277,7 +278,7 @@ struct mst_plan {
     }
     NotesDesc reloc(NotesDesc n, int k) const {
         const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
-        n.oct_off += a; n.deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
+        n.oct_off += a; n.deg_off += a; n.rt_oct_off += a; n.rt_deg_off += a; n.it_oct_off += a; n.it_deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
         n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += t; n.part_off += t; n.stats_off += t;
         return n;
     }
@@ -517,6 +518,90 @@ struct mst_plan {
         return out;
     }
 
+    // One column block of a Linear whose input is a broadcast-concat (style/utils/pytorch.py:54-65 + nn.Linear):
+    //   out[:, col0 : col0 + N] (+)= x (rows x kb) . W[:, k0 : k0 + kb]^T  [+ bias],   no activation.
+    // W is the full (N x Kfull) parameter; the bias is the Linear's parameter bias (bname), a one-row activation tensor
+    // (bias_act: its gradient is the column sum of dY) or absent.  The concat itself is never formed: the caller adds the
+    // blocks' outputs where it consumes them.  Backward: weight-gradient block through a 2-D slab entry, dx += dY . W block.
+    void linear_part(int stage, const T& x, bool xgrad, const std::string& wname, int k0, int Kfull, const std::string& bname,
+                     const T* bias_act, int N, const T& out, int col0) {
+        const int rows = x.rows, kb = x.cols;
+        const int64_t woff = pt.off(wname) + k0;
+        Op op; op.stage = stage;
+        {
+            GemmDesc g{}; g.M = rows; g.N = N; g.K = kb; g.ksplit = 1;
+            g.A.kind = OPK_DENSE; g.A.space = SP_WS; g.A.off = x.off; g.A.si = x.ld; g.A.sj = 1; g.A.ones_at = -1; g.A.kfast = 1;
+            g.B.kind = OPK_DENSE; g.B.space = SP_PAR; g.B.off = woff; g.B.si = 1; g.B.sj = Kfull; g.B.ones_at = -1; g.B.kfast = 1;
+            g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = ACT_NONE; g.out.off = out.off + col0;
+            g.out.bias_space = -1;
+            if (!bname.empty()) { g.out.bias_space = SP_PAR; g.out.bias_off = pt.off(bname); }
+            else if (bias_act) { g.out.bias_space = SP_WS; g.out.bias_off = bias_act->off + col0; }
+            op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
+            gemms.push_back(g);
+        }
+        const bool pbias = !bname.empty();
+        {   // dW block | db  =  dY^T [X | 1]
+            GemmDesc w{}; w.M = N; w.N = kb + (pbias ? 1 : 0); w.K = rows; w.ksplit = splits_for(rows);
+            w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = out.off + col0; w.A.si = 1; w.A.sj = out.ld; w.A.ones_at = -1; w.A.kfast = 0;
+            w.B.kind = OPK_DENSE; w.B.space = SP_WS; w.B.off = x.off; w.B.si = x.ld; w.B.sj = 1; w.B.ones_at = pbias ? kb : -1; w.B.kfast = 0;
+            const int64_t stride = (int64_t)N * kb + N;
+            const int64_t slab = tmp(stride * w.ksplit);
+            w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = kb; w.out.bias_space = -1;
+            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
+            gemms.push_back(w);
+            SlabEntry e{woff, slab, stride, N * kb, w.ksplit}; e.width = kb; e.dst_ld = Kfull;
+            slabs[stage_idx(stage)].push_back(e);
+            if (pbias) slabs[stage_idx(stage)].push_back(SlabEntry{pt.off(bname), slab + (int64_t)N * kb, stride, N, w.ksplit});
+        }
+        if (xgrad) {
+            GemmDesc a{}; a.M = rows; a.N = kb; a.K = N; a.ksplit = 1;
+            a.A.kind = OPK_DENSE; a.A.space = SP_GRAD; a.A.off = out.off + col0; a.A.si = out.ld; a.A.sj = 1; a.A.ones_at = -1; a.A.kfast = 1;
+            a.B.kind = OPK_DENSE; a.B.space = SP_PAR; a.B.off = woff; a.B.si = Kfull; a.B.sj = 1; a.B.ones_at = -1; a.B.kfast = 0;
+            a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = x.off; a.out.ldc = x.ld; a.out.bias_space = -1; a.out.act = ACT_NONE;
+            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, kb), 1});
+            gemms.push_back(a);
+        }
+        if (bias_act) column_sum(op, out.off + col0, out.ld, rows, N, bias_act->off + col0);
+        ops.push_back(op);
+    }
+
+    // backward helper: g[dst_off .. + width) += sum over `rows` rows of g[src_off + r * src_ld .. + width)
+    void column_sum(Op& op, int64_t src_off, int src_ld, int rows, int width, int64_t dst_off) {
+        SegRedDesc r{}; r.src_off = src_off; r.src_ld = src_ld; r.start = 0; r.width = width; r.dst_off = dst_off; r.dst_ld = width; r.nidx = 1;
+        const int rs[4] = {rows, 1, 1, 1};
+        for (int q = 0; q < 4; ++q) { r.d[q] = rs[q]; r.s[q] = 0; r.kd[q] = 1; }
+        r.nchunk = (rows + 63) / 64;
+        int stage2 = 0;
+        if (r.nchunk > 1) { r.part_off = tmp((int64_t)r.nchunk * width); stage2 = (width + 255) / 256; }
+        op.bwd.push_back(Step{K_SEGRED, (int)segreds.size(), 1, r.nidx * r.nchunk, stage2});
+        segreds.push_back(r);
+    }
+
+    // backward of "z[c, q] = rt[q] + it[c]" (rows c-major, `width` columns): g_rt[q] += sum_c g_z[c, q], g_it[c] += sum_q g_z[c, q]
+    void bcast_add_bwd(int stage, const T& gz, int Cn, int Qn, const T& rt, const T& it) {
+        Op op; op.stage = stage;
+        const int first = (int)segreds.size();
+        int maxidx = 1, stage2 = 0;
+        for (int which = 0; which < 2; ++which) {
+            SegRedDesc r{}; r.src_off = gz.off; r.src_ld = gz.ld; r.start = 0; r.width = gz.cols;
+            const T& dst = which ? it : rt;
+            r.dst_off = dst.off; r.dst_ld = dst.ld;
+            const int rs[4] = {Cn, Qn, 1, 1};
+            for (int q = 0; q < 4; ++q) { r.d[q] = rs[q]; r.s[q] = 0; r.kd[q] = 1; }
+            if (which) { r.s[0] = 1; r.kd[0] = Cn; r.nidx = Cn; r.nchunk = (Qn + 63) / 64; }      // keep c, reduce q
+            else { r.s[1] = 1; r.kd[1] = Qn; r.nidx = Qn; r.nchunk = (Cn + 63) / 64; }            // keep q, reduce c
+            if (r.nchunk > 1) {
+                r.part_off = tmp((int64_t)r.nidx * r.nchunk * r.width);
+                const int b2 = (r.nidx * r.width + 255) / 256;
+                if (b2 > stage2) stage2 = b2;
+            }
+            if (r.nidx * r.nchunk > maxidx) maxidx = r.nidx * r.nchunk;
+            segreds.push_back(r);
+        }
+        op.bwd.push_back(Step{K_SEGRED, first, 2, maxidx, stage2});
+        ops.push_back(op);
+    }
+
     void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out) {
         CombineDesc c{}; c.Cn = Cn; c.rows = rows; c.cols = cols; c.ld = ld; c.x_off = x_off; c.cs = cs; c.out_off = out.off;
         c.stats_off = tmp(64); c.part_off = tmp(COMBINE_MAXBLK * (COMBINE_MAXC + 1));
@@ -704,17 +789,32 @@ void mst_plan::build() {
     T psa_sl = linear(AP, style, true, m + ".style_linear", z.PSA_SL, ACT_LEAKY);
     T psa_rl = linear(AP, rhythm, true, m + ".rhythm_linear", z.PSA_RL, ACT_LEAKY);
     T psa_il = linear(AP, instr, false, m + ".instruments_linear", z.PSA_IL, ACT_LEAKY);
-    const int rsCQF[4] = {C, Q_ * NF, 1, 1};
-    T acat = gather(AP, rsCQF, {seg0(psa_sl), seg(psa_rl, 0, 1, 0, 0), seg(psa_il, 1, 0, 0, 0)});
-    T lo = linear(AP, acat, true, m + ".octave_linear", NPF * 6 * NOCT, ACT_LEAKY);
-    T ld_ = linear(AP, acat, true, m + ".scale_degree_linear", NPF * 6 * NDEG, ACT_LEAKY);
+    // octave_linear / scale_degree_linear (88 -> 240 / 210) act on cat_with_broadcast([style (1), rhythm (q, f), instrument (c)]):
+    // per row that is 39 600 multiply-adds of which all but the rhythm block repeat for every row.  The pre-activations
+    // decompose exactly into z[c, qf] = rt[qf] + it[c] (it = instrument block + style block + bias), three small column-block
+    // GEMMs each (linear_part); the note kernels add and activate on the fly, and the (positions x 450) octave / degree tensors
+    // and the (positions x 88) concat are never written.  The backward note kernel leaves dL/dz per row; its column sums over c
+    // and over qf are the gradients of rt and it.
+    const int KA = z.PSA_SL + z.PSA_RL + z.PSA_IL, QF_ = Q_ * NF;
+    T rt_x[2], it_x[2], gz_x[2];
+    for (int which = 0; which < 2; ++which) {
+        const std::string lin = m + (which ? ".scale_degree_linear" : ".octave_linear");
+        const int Nw = NPF * 6 * (which ? NDEG : NOCT);
+        T sb = newT(1, Nw);
+        it_x[which] = newT(C, Nw); rt_x[which] = newT(QF_, Nw);
+        linear_part(AP, psa_sl, true, lin + ".weight", 0, KA, lin + ".bias", nullptr, Nw, sb, 0);
+        linear_part(AP, psa_il, true, lin + ".weight", z.PSA_SL + z.PSA_RL, KA, "", &sb, Nw, it_x[which], 0);
+        linear_part(AP, psa_rl, true, lin + ".weight", z.PSA_SL, KA, "", nullptr, Nw, rt_x[which], 0);
+        gz_x[which] = newT(P_ * NF, Nw);                   // only its gradient slot is used
+        bcast_add_bwd(AP, gz_x[which], C, QF_, rt_x[which], it_x[which]);
+    }
     T ml = rowlin(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
-        n.oct_off = lo.off; n.deg_off = ld_.off; n.ml_off = ml.off;
+        n.rt_oct_off = rt_x[0].off; n.rt_deg_off = rt_x[1].off; n.it_oct_off = it_x[0].off; n.it_deg_off = it_x[1].off; n.ml_off = ml.off;
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
-        n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = lo.off; n.g_deg_off = ld_.off; n.g_ml_off = ml.off;
+        n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = gz_x[0].off; n.g_deg_off = gz_x[1].off; n.g_ml_off = ml.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
         const int qf = Q_ * NF;
         // forward: a workgroup per qf up to the cap.  backward: a wave per qf, four per workgroup, one slab row per wave
@@ -795,6 +895,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             operand_acc(v, g.A, g.M, g.K, -1);
             operand_acc(v, g.B, g.K, g.N, g.B.ones_at);
             const OutSpec& o = g.out;
+            if (o.bias_space >= 0) acc_add(v, o.bias_space, o.bias_off, g.N, false);       // a bias row that is an activation (linear_part)
             if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
             else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true, true, g.N == o.ldc || g.M == 1);
             else if (o.kind == OUT_CONV) acc_add(v, o.space, o.off, (int64_t)(g.M / NOCT) * o.ldc, true);
@@ -909,8 +1010,10 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             const int64_t rows = me ? (int64_t)n.C * n.Q : (int64_t)n.C * n.Q * NF;
             const int ow = me ? NOCT * n.W : NOCT * 30, dw = me ? NDEG * n.W : NDEG * 30, outw = me ? n.W : NPF;
             const int64_t mln = (int64_t)n.Q * NF * NPN * n.ML;
-            acc_add(v, SP_WS, n.oct_off, rows * ow, false);
-            acc_add(v, SP_WS, n.deg_off, rows * dw, false);
+            acc_add(v, SP_WS, n.rt_oct_off, (int64_t)n.Q * NF * ow, false);
+            acc_add(v, SP_WS, n.rt_deg_off, (int64_t)n.Q * NF * dw, false);
+            acc_add(v, SP_WS, n.it_oct_off, (int64_t)n.C * ow, false);
+            acc_add(v, SP_WS, n.it_deg_off, (int64_t)n.C * dw, false);
             if (!me) acc_add(v, SP_WS, n.ml_off, mln, false);
             acc_add(v, SP_WS, n.out_off, pos * outw, !bwd);
             if (bwd) {
