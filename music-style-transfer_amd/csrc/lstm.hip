@@ -73,17 +73,25 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
             }
         } else if (tid < G) {
             // thread per gate row over the transposed copy: lane-contiguous (coalesced) reads, 4 chains
+            // summed as four quarters of k, each four interleaved chains, then (q0 + q1) + (q2 + q3): the association of the
+            // multi-workgroup flavour below, so a clip's activations are bit-identical in one-clip and batched plans
             const float* wt = tmp + d.whht_off + tid;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int k = 0;
-            for (; k + 4 <= H; k += 4) {
-                a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
-                a1 = fmaf(wt[(int64_t)(k + 1) * G], h_s[k + 1], a1);
-                a2 = fmaf(wt[(int64_t)(k + 2) * G], h_s[k + 2], a2);
-                a3 = fmaf(wt[(int64_t)(k + 3) * G], h_s[k + 3], a3);
+            const int KQ = (H % 16 == 0) ? H / 4 : H;
+            float qs[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int qq = 0; qq * KQ < H; ++qq) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int k = qq * KQ;
+                const int ke = k + KQ;
+                for (; k + 4 <= ke; k += 4) {
+                    a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
+                    a1 = fmaf(wt[(int64_t)(k + 1) * G], h_s[k + 1], a1);
+                    a2 = fmaf(wt[(int64_t)(k + 2) * G], h_s[k + 2], a2);
+                    a3 = fmaf(wt[(int64_t)(k + 3) * G], h_s[k + 3], a3);
+                }
+                for (; k < ke; ++k) a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
+                qs[qq] = (a0 + a1) + (a2 + a3);
             }
-            for (; k < H; ++k) a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
-            z_s[tid] = (a0 + a1) + (a2 + a3);
+            z_s[tid] = (qs[0] + qs[1]) + (qs[2] + qs[3]);
         }
         MST_LDS_BARRIER();
         if (tid < H) {
@@ -112,7 +120,10 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
     if (bi >= d.B) return;
     const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
     __shared__ float dz_s[1024];
-    __shared__ float red_s[1024];      // four partial sums of dh_{t-1} per hidden unit, consumed by the next step
+    // partial sums of dh_{t-1} per hidden unit, consumed by the next step: four (one per gate) in the register flavour,
+    // sixteen 48-row chunks in the L2 flavour (the association of the multi-workgroup kernel: bit-identical results)
+    __shared__ float red_s[REG ? 1024 : 16 * 256];
+    const bool chunked = !REG && (d.H % 16 == 0) && d.H <= 256;
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* tmp = b.p[SP_TMP];
     float* gr = b.p[SP_GRAD];
@@ -125,7 +136,8 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
             w[jj] = jj < H ? v : 0.f;
         }
     }
-    red_s[tid] = 0.f;
+    if (REG) red_s[tid] = 0.f;
+    else for (int i = tid; i < 16 * 256; i += blockDim.x) red_s[i] = 0.f;
     float dc_next = 0.f;
     // streamed operands of a step (saved gates, cell states, incoming gradient), prefetched one step ahead
     float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -149,7 +161,13 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
         if (tid < H) {
             if (step > 0) LSTM_LOAD(step - 1, nx)
             const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], tc = sv[4], cprev = sv[5];
-            const float dh = sv[6] + ((red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]));
+            float dhr;
+            if (chunked) {
+                dhr = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dhr += red_s[q * H + tid];
+            } else dhr = (red_s[tid] + red_s[H + tid]) + (red_s[2 * H + tid] + red_s[3 * H + tid]);
+            const float dh = sv[6] + dhr;
             const float dc = dc_next + dh * og * (1.f - tc * tc);
             const float dzi = dc * gg * ig * (1.f - ig);
             const float dzf = dc * cprev * fg * (1.f - fg);
@@ -162,6 +180,7 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
         }
         MST_LDS_BARRIER();
         float acc = 0.f;
+        float cacc[4] = {0.f, 0.f, 0.f, 0.f};
         if (tid < G) {   // dh_{t-1}[k] = sum_j W_hh[j,k] dz[j], four partial sums per k (summed by the next step)
             if (REG) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -175,34 +194,228 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
                 }
                 acc = (a0 + a1) + (a2 + a3);
             } else {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const float* wc = whh + (int64_t)part * H * H + kk;      // coalesced along kk
                 const float* dzp = dz_s + part * H;
-                int jj = 0;
-                for (; jj + 4 <= H; jj += 4) {
-                    a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
-                    a1 = fmaf(wc[(int64_t)(jj + 1) * H], dzp[jj + 1], a1);
-                    a2 = fmaf(wc[(int64_t)(jj + 2) * H], dzp[jj + 2], a2);
-                    a3 = fmaf(wc[(int64_t)(jj + 3) * H], dzp[jj + 3], a3);
+                const int CH = chunked ? H / 4 : H;                      // rows per chunk (48 at H = 192)
+                for (int ci = 0; ci * CH < H; ++ci) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    int jj = ci * CH;
+                    const int je = jj + CH;
+                    for (; jj + 4 <= je; jj += 4) {
+                        a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
+                        a1 = fmaf(wc[(int64_t)(jj + 1) * H], dzp[jj + 1], a1);
+                        a2 = fmaf(wc[(int64_t)(jj + 2) * H], dzp[jj + 2], a2);
+                        a3 = fmaf(wc[(int64_t)(jj + 3) * H], dzp[jj + 3], a3);
+                    }
+                    for (; jj < je; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
+                    acc = (a0 + a1) + (a2 + a3);
+                    if (chunked) cacc[ci] = acc;
                 }
-                for (; jj < H; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
-                acc = (a0 + a1) + (a2 + a3);
             }
         }
         if (tid < H) {
 #pragma unroll
             for (int q = 0; q < 7; ++q) sv[q] = nx[q];     // the prefetch landed under the matvec above
         }
-        if (tid < G) red_s[tid] = acc;                    // phase A's reads of red_s ended before the barrier above
+        if (tid < G) {                                    // phase A's reads of red_s ended before the barrier above
+            if (chunked) {
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) red_s[(4 * part + ci) * H + kk] = cacc[ci];
+            } else red_s[tid] = acc;
+        }
         MST_LDS_BARRIER();
     }
 #undef LSTM_LOAD
 }
 
+// ---- multi-workgroup flavour -------------------------------------------------------------------
+// One clip, H = 192 (StyleEncoder.bars_lstm), batch 1: a single workgroup streamed all 590 KB of W_hh from L2 every step
+// (one CU's L2 bandwidth: 5.4 us per step, 2 x 82 us per iteration — a fifth of the whole iteration).  Here LSTM_NB = 12
+// workgroups own 16 hidden units each: their 64 gate rows (forward) / 16 columns (backward) of W_hh live in registers for
+// the whole sequence (48 floats per lane), and per step they exchange only h_t (192 floats) or dz_t (768 floats) through
+// tagged 8-byte granules {epoch, value}: one relaxed agent-scope (sc1) store publishes a value, consumers poll the granule
+// until its tag is this step's epoch — the data is its own flag, no fence, no separate counter
+// (cdna_hip_programming.md Guideline 16, R2).  Buffers alternate with the step's parity: a workgroup can publish step
+// t + 1 only after it has consumed every workgroup's step t, so the slot it overwrites (t - 1) is no longer needed by
+// anyone.  Tags are cleared before every forward (lstm_transpose_kernel): epochs restart at 1 in every launch.  Every spin
+// is bounded: a workgroup that never sees its tag yields NaNs instead of hanging the GPU.
+// The 12 (x 2 concurrent iterations) workgroups are far below the chip's residency, but dispatch order is still undefined:
+// nothing here depends on which workgroup starts first.
+#ifndef HIPSIM
+typedef unsigned long long lstm_gran_t;
+__device__ __forceinline__ void gran_store(lstm_gran_t* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((lstm_gran_t)tag << 32) | (lstm_gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gran_wait(const lstm_gran_t* g, unsigned tag) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const lstm_gran_t x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __builtin_nanf("");
+}
+
+__global__ __launch_bounds__(256) void lstm_multi_fwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];
+    constexpr int H = LSTM_MH, G = 4 * H, HU = H / LSTM_NB, KQ = H / 4;       // 16 units per workgroup, 48 k per lane
+    const int wg = blockIdx.x, tid = threadIdx.x;
+    const int row_l = tid >> 2, kq = tid & 3;                                  // gate row of this workgroup / quarter of k
+    const int gate = row_l / HU, u = row_l - gate * HU;
+    const int j = gate * H + wg * HU + u;                                      // row of W_hh
+    __shared__ __attribute__((aligned(16))) float h_s[H];
+    __shared__ float z_s[4 * HU];
+    const float* whh = b.p[SP_PAR] + d.whh_off;
+    const float* zx = b.p[SP_WS] + d.zx_off;
+    float* ws = b.p[SP_WS];
+    float* tmp = b.p[SP_TMP];
+    lstm_gran_t* xch = reinterpret_cast<lstm_gran_t*>(tmp + d.xch_off);        // [2][H]
+    float w[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ / 4; ++i) {
+        const float4 t4 = *reinterpret_cast<const float4*>(whh + (int64_t)j * H + kq * KQ + 4 * i);
+        w[4 * i] = t4.x; w[4 * i + 1] = t4.y; w[4 * i + 2] = t4.z; w[4 * i + 3] = t4.w;
+    }
+    // unit lanes: tid < HU owns hidden unit k = wg * HU + tid
+    const int k = wg * HU + (tid < HU ? tid : 0);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, zq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = d.reverse ? d.S - 1 : 0;
+    if (tid < HU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bias[q] = b.p[SP_PAR][d.bhh_off + q * H + k]; zq[q] = zx[(int64_t)s0 * G + q * H + k]; }
+    }
+    float c = 0.f, hprev = 0.f;
+    for (int step = 0; step < d.S; ++step) {
+        const int s = d.reverse ? d.S - 1 - step : step;
+        float zn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tid < HU && step + 1 < d.S) {                    // next step's zx row: in flight under this step
+            const int sn = d.reverse ? s - 1 : s + 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zn[q] = zx[(int64_t)sn * G + q * H + k];
+        }
+        // h_{t-1} of every workgroup (tag = step: published with epoch (step - 1) + 1)
+        if (tid < H) h_s[tid] = step == 0 ? 0.f : gran_wait(xch + ((step - 1) & 1) * H + tid, (unsigned)step);
+        __syncthreads();
+        if (tid < HU) hprev = h_s[k];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KQ; i += 4) {
+            const float4 h4 = *reinterpret_cast<const float4*>(h_s + kq * KQ + i);
+            a0 = fmaf(w[i], h4.x, a0); a1 = fmaf(w[i + 1], h4.y, a1); a2 = fmaf(w[i + 2], h4.z, a2); a3 = fmaf(w[i + 3], h4.w, a3);
+        }
+        float zsum = (a0 + a1) + (a2 + a3);
+        zsum += __shfl_xor(zsum, 1);
+        zsum += __shfl_xor(zsum, 2);
+        if (kq == 0) z_s[row_l] = zsum;
+        __syncthreads();
+        if (tid < HU) {
+            const int64_t row = s;
+            const float ig = sigm(z_s[tid] + zq[0] + bias[0]), fg = sigm(z_s[HU + tid] + zq[1] + bias[1]);
+            const float gg = tanh_fast(z_s[2 * HU + tid] + zq[2] + bias[2]), og = sigm(z_s[3 * HU + tid] + zq[3] + bias[3]);
+            c = fg * c + ig * gg;
+            const float tc = tanh_fast(c);
+            const float h = og * tc;
+            gran_store(xch + (step & 1) * H + k, (unsigned)(step + 1), h);      // first: the other workgroups wait for it
+            tmp[d.hprev_off + row * H + k] = hprev;
+            tmp[d.tc_off + row * H + k] = tc;
+            float* g = tmp + d.gates_off + row * G;
+            g[k] = ig; g[H + k] = fg; g[2 * H + k] = gg; g[3 * H + k] = og;
+            tmp[d.c_off + row * H + k] = c;
+            ws[d.out_off + row * d.out_ld + k] = h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_multi_bwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];
+    constexpr int H = LSTM_MH, G = 4 * H, HU = H / LSTM_NB, JQ = 16, JW = G / JQ;   // 16 j-chunks of 48 gate rows
+    const int wg = blockIdx.x, tid = threadIdx.x;
+    const int kk = tid & (HU - 1), jq = tid / HU;             // lane (jq, kk) sums W_hh[jq*48 + i][wg*16 + kk] dz[jq*48 + i]
+    __shared__ __attribute__((aligned(16))) float dz_s[G];
+    __shared__ float part_s[JQ][HU + 1];
+    const float* whh = b.p[SP_PAR] + d.whh_off;
+    const float* tmp = b.p[SP_TMP];
+    float* gr = b.p[SP_GRAD];
+    lstm_gran_t* xch = reinterpret_cast<lstm_gran_t*>(b.p[SP_TMP] + d.xch_off) + 2 * H;     // [2][G], behind the forward's
+    float w[JW];
+#pragma unroll
+    for (int i = 0; i < JW; ++i) w[i] = whh[(int64_t)(jq * JW + i) * H + wg * HU + kk];
+    const int k = wg * HU + (tid < HU ? tid : 0);
+    float dc_next = 0.f, dh_rec = 0.f;
+    float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define LSTM_MLOAD(STEP, DST)                                                                           \
+    {                                                                                                   \
+        const int s_ = d.reverse ? d.S - 1 - (STEP) : (STEP);                                           \
+        const int sp_ = d.reverse ? s_ + 1 : s_ - 1;                                                    \
+        const float* g_ = tmp + d.gates_off + (int64_t)s_ * G;                                          \
+        DST[0] = g_[k]; DST[1] = g_[H + k]; DST[2] = g_[2 * H + k]; DST[3] = g_[3 * H + k];             \
+        DST[4] = tmp[d.tc_off + (int64_t)s_ * H + k];                                                   \
+        DST[5] = (STEP) > 0 ? tmp[d.c_off + (int64_t)sp_ * H + k] : 0.f;                                \
+        DST[6] = gr[d.gout_off + (int64_t)s_ * d.out_ld + k];                                           \
+    }
+    if (tid < HU) LSTM_MLOAD(d.S - 1, sv)
+    for (int step = d.S - 1; step >= 0; --step) {
+        const int s = d.reverse ? d.S - 1 - step : step;
+        const unsigned epoch = (unsigned)(d.S - step);        // 1, 2, ... in execution order
+        const int par = (int)(epoch & 1);
+        float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tid < HU) {
+            if (step > 0) LSTM_MLOAD(step - 1, nx)
+            const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], tc = sv[4], cprev = sv[5];
+            const float dh = sv[6] + dh_rec;
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float dzi = dc * gg * ig * (1.f - ig);
+            const float dzf = dc * cprev * fg * (1.f - fg);
+            const float dzg = dc * ig * (1.f - gg * gg);
+            const float dzo = dh * tc * og * (1.f - og);
+            dc_next = dc * fg;
+            if (step > 0) {                                   // the last step's dz feeds no further recurrence
+                lstm_gran_t* x = xch + par * G;
+                gran_store(x + k, epoch, dzi); gran_store(x + H + k, epoch, dzf);
+                gran_store(x + 2 * H + k, epoch, dzg); gran_store(x + 3 * H + k, epoch, dzo);
+            }
+            float* gz = gr + d.gzx_off + (int64_t)s * G;
+            gz[k] = dzi; gz[H + k] = dzf; gz[2 * H + k] = dzg; gz[3 * H + k] = dzo;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) sv[q] = nx[q];
+        }
+        if (step == 0) break;
+#pragma unroll
+        for (int i = 0; i < G / 256; ++i) dz_s[tid + 256 * i] = gran_wait(xch + par * G + tid + 256 * i, epoch);
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < JW; i += 4) {
+            const float4 z4 = *reinterpret_cast<const float4*>(dz_s + jq * JW + i);
+            a0 = fmaf(w[i], z4.x, a0); a1 = fmaf(w[i + 1], z4.y, a1); a2 = fmaf(w[i + 2], z4.z, a2); a3 = fmaf(w[i + 3], z4.w, a3);
+        }
+        part_s[jq][kk] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (tid < HU) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) a += part_s[q][tid];
+            dh_rec = a;
+        }
+        __syncthreads();                                      // part_s / dz_s are rewritten by the next step
+    }
+#undef LSTM_MLOAD
+}
+
+__global__ __launch_bounds__(256) void lstm_multi_clear_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];
+    if (!d.multi) return;
+    float* x = b.p[SP_TMP] + d.xch_off;
+    const int n = 2 * (2 * d.H + 8 * d.H);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = 0.f;
+}
+#endif
+
 // W_hh (4H x H) -> W_hh^T (H x 4H) so that the H > 64 forward reads it lane-contiguously
 __global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __restrict__ descs, Bases b) {
     const LstmDesc d = descs[blockIdx.y];        // by value: no descriptor re-reads after the per-step barriers
-    if (d.H <= 64) return;
+    if (d.H <= 64 || d.multi) return;
     const int G = 4 * d.H, n = G * d.H;
     const float* w = b.p[SP_PAR] + d.whh_off;
     float* wt = b.p[SP_TMP] + d.whht_off;
@@ -212,8 +425,14 @@ __global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __r
     }
 }
 
-int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s) {
+int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0 || maxH <= 64) return 0;
+#ifndef HIPSIM
+    if (multi) {       // the multi-workgroup flavour needs no transposed copy; its exchange tags restart from zero
+        hipLaunchKernelGGL(lstm_multi_clear_kernel, dim3(4, count), dim3(256), 0, s, dev_descs, b);
+        return (int)hipGetLastError();
+    }
+#endif
     int nb = (4 * maxH * maxH + 255) / 256;
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(lstm_transpose_kernel, dim3(nb, count), dim3(256), 0, s, dev_descs, b);
@@ -225,8 +444,14 @@ static int block_for(int maxH) {
     return t < 64 ? 64 : t;
 }
 
-int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s) {
+int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
+#ifndef HIPSIM
+    if (multi) {
+        hipLaunchKernelGGL(lstm_multi_fwd_kernel, dim3(LSTM_NB, count), dim3(256), 0, s, dev_descs, b);
+        return (int)hipGetLastError();
+    }
+#endif
     if (maxH <= 64)
         hipLaunchKernelGGL((lstm_fwd_kernel<true>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
     else
@@ -234,8 +459,14 @@ int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Ba
     return (int)hipGetLastError();
 }
 
-int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s) {
+int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
+#ifndef HIPSIM
+    if (multi) {
+        hipLaunchKernelGGL(lstm_multi_bwd_kernel, dim3(LSTM_NB, count), dim3(256), 0, s, dev_descs, b);
+        return (int)hipGetLastError();
+    }
+#endif
     if (maxH <= 64)
         hipLaunchKernelGGL((lstm_bwd_kernel<true>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
     else

@@ -133,7 +133,13 @@ struct LstmDesc {
     int64_t gout_off;    // gradient of out (same ld)                      [SP_WS]
     int64_t gzx_off;     // gradient of zx, written (=)
     int64_t whht_off;    // [SP_TMP] W_hh transposed (H x 4H), built per forward when H > 64
+    // multi-workgroup flavour (one-clip plans, H = 192, batch 1): the gate rows are split over LSTM_NB workgroups that exchange
+    // h_t (forward) / dz_t (backward) through tagged 8-byte granules
+    int32_t multi;
+    int64_t xch_off;     // [SP_TMP] forward 2 x H granules, then backward 2 x 4H granules (8 bytes each)
 };
+#define LSTM_NB 12       // workgroups per sequence in the multi-workgroup flavour: 16 hidden units (64 gate rows) each at H = 192
+#define LSTM_MH 192
 
 // ---- combine (style/model.py:796-815): out = sum_c x_c n_c / sum_c n_c
 #define COMBINE_MAXC 32
@@ -219,9 +225,9 @@ int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, i
 int gemm_tile_edge(int mfma);
 int gemm_blocks(const GemmDesc& g, int mfma);       // workgroups of one member (tiles / run x k-splits)
 int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip, int clips, int stage2_blocks, Bases b, hipStream_t s);
-int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, Bases b, hipStream_t s);
-int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
-int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, Bases b, hipStream_t s);
+int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, int multi, Bases b, hipStream_t s);
+int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s);
+int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s);
 int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 // `count` descriptors of identical shape (the clips of a batched plan), blockIdx.y = descriptor

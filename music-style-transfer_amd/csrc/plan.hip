@@ -264,7 +264,7 @@ struct mst_plan {
     LstmDesc reloc(LstmDesc l, int k) const {           // whht (W_hh transposed) is shared: parameters only
         const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
         l.zx_off += a; l.out_off += a; l.gout_off += a; l.gzx_off += a;
-        l.gates_off += t; l.c_off += t; l.hprev_off += t; l.tc_off += t;
+        l.gates_off += t; l.c_off += t; l.hprev_off += t; l.tc_off += t; l.xch_off += t;
         return l;
     }
     CombineDesc reloc(CombineDesc c, int k) const {
@@ -469,6 +469,10 @@ struct mst_plan {
             l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H); l.tc_off = tmp(n * H);
             l.gout_off = sp.out.off + sp.coloff; l.gzx_off = zxs[i].off;
             l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
+#ifndef HIPSIM      // the interpreter runs workgroups one after another: a kernel whose workgroups wait for each other cannot run there
+            l.multi = (K() == 1 && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
+#endif
+            l.xch_off = l.multi ? tmp(2 * (2 * H + 2 * 4 * H)) : 0;
             lstms.push_back(l);
             if (sp.B > maxB) maxB = sp.B;
             if (H > maxH) maxH = H;
@@ -923,6 +927,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
         }
         case K_LSTM_T: {
             const LstmDesc& l = lstms[s.first + i];
+            if (l.multi) { acc_add(v, SP_TMP, l.xch_off, 2 * (2 * l.H + 8 * l.H), true); break; }
             if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, true);
             break;
         }
@@ -935,7 +940,8 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             acc_add(v, SP_TMP, l.c_off, n * l.H, true);
             acc_add(v, SP_TMP, l.hprev_off, n * l.H, true);
             acc_add(v, SP_TMP, l.tc_off, n * l.H, true);
-            if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, false);
+            if (l.multi) acc_add(v, SP_TMP, l.xch_off, 2 * (2 * l.H + 8 * l.H), true);
+            else if (l.H > 64) acc_add(v, SP_TMP, l.whht_off, (int64_t)4 * l.H * l.H, false);
             break;
         }
         case K_LSTM_B: {
@@ -946,6 +952,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             acc_add(v, SP_TMP, l.tc_off, n * l.H, false);
             acc_add(v, SP_GRAD, l.gout_off, (n - 1) * l.out_ld + l.H, false);
             acc_add(v, SP_GRAD, l.gzx_off, n * 4 * l.H, true);
+            if (l.multi) acc_add(v, SP_TMP, l.xch_off, 2 * (2 * l.H + 8 * l.H), true);
             break;
         }
         case K_COMB_F: case K_COMB_B: {
@@ -1327,9 +1334,9 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_GEMM: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count / p->K(), s.a, p->K(), s.b, b, st);
-    case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, b, st);
-    case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
-    case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, b, st);
+    case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, p->s_lstms[s.first].multi, b, st);
+    case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, p->s_lstms[s.first].multi, b, st);
+    case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, p->s_lstms[s.first].multi, b, st);
     case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
     case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
     case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
