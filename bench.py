@@ -200,6 +200,68 @@ def batched_leg(native, nat, dev, flat, K, passes, warm):
                 roofline=roof, kernel_breakdown=rows)
 
 
+LONG_CLIP = dict(C=8, R=151, T=4)       # BASELINE.json configs[4] mapped per SURVEY.md 8(d): 5 min at 120 bpm + 1 = 151 bars, 8 channels
+
+
+def tiled_leg(native, nat, dev, flat, dist, rank, world, iters, warm):
+    """BASELINE.json configs[4]: ONE long clip (C=8, R=151, T=4) whose bars are tiled over the ranks: every
+    rank computes the per-position work of its contiguous bar tile, the bar-level chains run replicated, and the iteration
+    is a sequence of phases with small all-reduces (SUM) in between (mst_tiled_phase), then the flat-gradient all-reduce and
+    Adam.  A step = one training iteration of the whole clip (strong scaling: the clip is fixed, the tiles shrink)."""
+    from tools.synth import synth_clip
+    C_, R_, T_ = LONG_CLIP['C'], LONG_CLIP['R'], LONG_CLIP['T']
+    base, extra = divmod(R_, world)
+    rows = base + (1 if rank < extra else 0)
+    r0 = rank * base + min(rank, extra)
+    dims = nat.Dims(**LONG_CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+    plan = nat.Plan(native, dims, dev, tile_r0=r0, tile_rows=rows)
+    c = synth_clip(9, C_, R_, T_, True)
+    plan.set_inputs(mode=c['mode'], bpm=c['bpm'], instr=c['instruments_features'], used=c['used_instruments'], bpm_target=float(c['bpm_int']))
+    xp = c['pitched'][:, :, r0:r0 + rows].contiguous().to(dev)
+    xu = c['unpitched'][:, :, r0:r0 + rows].contiguous().to(dev)
+    params = flat.to(dev)
+    g, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+    state = torch.zeros(4, device=dev)
+    losses = torch.zeros(nat.N_LOSSES, device=dev)
+    P = nat.ptr
+    n_x = [0]
+
+    def all_reduce(t):
+        n_x[0] += 1
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def iteration():
+        plan.tiled_train_iteration(params, g, xp, xu, losses, is_root=rank == 0, all_reduce=all_reduce)
+        if dist is not None:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        nat.check(native.lib.mst_adam_step(P(params), P(g), P(m), P(v), params.numel(), P(state), .01, .9, .999, 1e-8, 200, .9, 1,
+                                           nat.current_stream(dev)), 'mst_adam_step')
+
+    for _ in range(warm):
+        iteration()
+    n_x[0] = 0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.cpu()[0])
+    return dict(value=iters / dt, unit='iters/s', ms_per_step=dt / iters * 1e3, steps=iters, warmup=warm, scaling='strong',
+                config=dict(workload=f'one 5-min clip C={C_},R={R_},T={T_} (+percussion), bars tiled over {world} rank(s) '
+                                     f'(BASELINE.json configs[4]): fwd+loss+bwd+Adam every step, {n_x[0] // max(iters, 1)} in-iteration '
+                                     'all-reduces (SUM) of small workspace ranges + the flat-gradient all-reduce',
+                            bars_per_rank=rows, hip_graph=False, final_total_loss=float(losses.cpu()[0])))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,6 +280,9 @@ def main():
                     help='with the default one-clip workload on 1 GPU: also time this many clips in one batched plan (configs[2]) for '
                          'a few passes and report it as "batched" in the same JSON line; 0 = skip')
     ap.add_argument('--batched-passes', type=int, default=12)
+    ap.add_argument('--tile-bars', action='store_true',
+                    help='headline = BASELINE.json configs[4] instead: ONE long clip (C=8, R=151, T=4) with its bars tiled over the '
+                         '--gpus ranks (strong scaling)')
     ap.add_argument('--accum', choices=['streams', 'batched'], default='streams',
                     help='B = 1: run the iter_size = 2 accumulation iterations on two streams (default) or as one 2-clip batched pass')
     args = ap.parse_args()
@@ -249,6 +314,15 @@ def main():
     dims1 = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
     dims = nat.Dims(**CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1, clips=K)
     flat, table = init_params(native, dims1)
+    if args.tile_bars:
+        r = tiled_leg(native, nat, dev, flat, dist, rank, world, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(dict(metric='style-transfer opt iters/sec', value=r['value'], unit='iters/s', n_gpus=world, steps=args.steps,
+                                  warmup=args.warmup, ms_per_step=r['ms_per_step'], higher_is_better=True, scaling='strong',
+                                  vs_baseline=None, dtype='f32', data='synthetic', config=r['config'])))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     # B = 1: the one clip of this GPU (both accumulation iterations run on it, like the reference looping over a
     # one-song dataset); B > 1: B different clips
     clips = [synth_clip(rank * B + (k if B > 1 else 0), CLIP['C'], CLIP['R'], CLIP['T'], True) for k in range(K)]
@@ -382,6 +456,15 @@ def main():
                            launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 3,      # + 3 loss kernels
                            parallelism=f'dp{world} ({"RCCL" if args.backend == "nccl" else args.backend} all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
                            device_ms_per_step=dev_ms / args.steps, final_total_loss=final_loss))
+    if world > 1 and B == 1 and not batched:
+        # configs[4] beside the data-parallel headline: the long clip with its bars tiled over the same ranks (never lets the
+        # headline line fail)
+        try:
+            tl = tiled_leg(native, nat, dev, flat, dist, rank, world, 10, 2)
+        except Exception as e:                      # noqa: BLE001
+            tl = dict(error=repr(e))
+        if rank == 0:
+            out['tiled'] = tl
     if rank == 0:
         out['roofline'] = roof
         out['kernel_breakdown'] = table_rows

@@ -78,7 +78,11 @@ typedef struct {
                                  * launches of one kernel */
     int32_t gemm_run;           /* 64x64 tiling: output tiles one workgroup walks back to back; 0 = choose (1..8, keeping >= ~4096
                                  * workgroups per launch) */
-    int32_t reserved[5];        /* must be 0 */
+    int32_t tile_r0, tile_rows; /* bar tiling of ONE clip over several ranks (BASELINE.json configs[4]): this plan computes
+                                 * the per-position work of bars [tile_r0, tile_r0 + tile_rows) of the mst_dims.R bars; the bar-level
+                                 * chains run replicated.  tile_rows = 0: not tiled.  Run with mst_tiled_phase (clips must be 1);
+                                 * `pitched` / `unpitched` are then the tile's bars only: (1,C,tile_rows,T,10,56,5), (1,1,tile_rows,T,10,47,2) */
+    int32_t reserved[3];        /* must be 0 */
 } mst_plan_options;
 mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
 mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);
@@ -144,6 +148,17 @@ int32_t mst_total_loss_bwd(const float* pitched_pred, const float* pitched_targe
  * receives the SUM over the K clips (= K loop bodies at the same parameters). */
 int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
                             const float* pitched, const float* unpitched, float* losses, mst_stream stream);
+
+/* ---- one loop body (train-model.py:113-126) of a clip whose bars are tiled over ranks.  Every rank calls phase 0, 1, ...
+ * mst_tiled_phase_count() - 1 on its own plan / workspace / gparams; after a phase that returns *xlen > 0 the host all-reduces
+ * (SUM) ws[*xoff, *xoff + *xlen) over the ranks (torch.distributed / RCCL) before the next phase.  Afterwards gparams holds this
+ * rank's share of the clip's gradient: all-reduce (SUM) it like in data parallelism (train-model.py:126,151-153), then
+ * mst_adam_step.  is_root: exactly one rank passes 1 (it contributes the replicated song-info loss gradients).  losses:
+ * MST_N_LOSSES floats, identical on every rank. */
+int32_t mst_tiled_phase_count(const mst_plan* p);
+int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float* params, float* gparams, float* ws,
+                        const float* pitched, const float* unpitched, float* losses, int32_t is_root,
+                        mst_stream stream, int64_t* xoff, int64_t* xlen);
 
 /* ---- torch.optim.Adam(lr=.01) + StepLR(200,.9) + zero_grad (train-model.py:89-90,151-154)
  * over the flat buffers. state: 4 floats {step count t, lr_t/(1-b1^t), sqrt(1-b2^t), reserved} kept on the device so that

@@ -262,3 +262,55 @@ int launch_combine_bwd(const CombineDesc* dev, int count, int max_nblk, int all_
     hipLaunchKernelGGL(combine_bwd_apply_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
     return (int)hipGetLastError();
 }
+
+// ---- tiled plans: the halves of a combine on their own (the ranks' partial sums meet in between), strided row copies
+// and the fold / spread pair around an exchange (mst_common.h)
+int launch_combine_phase(const CombineDesc* dev, int nblk, int which, Bases b, hipStream_t s) {
+    if (which == 0) hipLaunchKernelGGL(combine_sumsq_kernel, dim3(nblk, 1), dim3(256), 0, s, dev, b);
+    else if (which == 1) hipLaunchKernelGGL(combine_apply_kernel, dim3(nblk, 1), dim3(256), 0, s, dev, b);
+    else if (which == 2) hipLaunchKernelGGL(combine_bwd_reduce_kernel, dim3(nblk, 1), dim3(256), 0, s, dev, b);
+    else hipLaunchKernelGGL(combine_bwd_apply_kernel, dim3(nblk, 1), dim3(256), 0, s, dev, b);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const CopyDesc* __restrict__ dp, int backward, Bases b) {
+    const CopyDesc d = dp[0];
+    const int total = d.na * d.nb * d.cols;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e % d.cols, ab = e / d.cols, bb = ab % d.nb, a = ab / d.nb;
+        const int64_t so = d.src_off + (int64_t)a * d.src_sa + (int64_t)bb * d.src_sb + j;
+        const int64_t dof = d.dst_off + (int64_t)a * d.dst_sa + (int64_t)bb * d.dst_sb + j;
+        if (!backward) b.p[SP_WS][dof] = b.p[SP_WS][so];
+        else { float* g = b.p[SP_GRAD] + so; const float v = b.p[SP_GRAD][dof]; *g = d.first ? v : *g + v; }
+    }
+}
+
+int launch_copy_rows(const CopyDesc* dev, const CopyDesc& host, int backward, Bases b, hipStream_t s) {
+    const int total = host.na * host.nb * host.cols;
+    int nb = (total + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) return 0;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(nb), dim3(256), 0, s, dev, backward, b);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void fold_kernel(const FoldDesc* __restrict__ dp, int spread, Bases b) {
+    const FoldDesc d = dp[0];
+    float* part = b.p[d.space] + d.part_off;
+    float* sum = b.p[SP_TMP] + d.sum_off;
+    for (int c = threadIdx.x; c < d.ncols; c += 64) {
+        if (!spread) {
+            float a = 0.f;
+            for (int r = 0; r < d.nrows; ++r) a += part[(int64_t)r * d.row_stride + (int64_t)c * d.col_stride];
+            sum[c] = a;
+        } else {
+            part[(int64_t)c * d.col_stride] = sum[c];
+            for (int r = 1; r < d.nrows; ++r) part[(int64_t)r * d.row_stride + (int64_t)c * d.col_stride] = 0.f;
+        }
+    }
+}
+
+int launch_fold(const FoldDesc* dev, int spread, Bases b, hipStream_t s) {
+    hipLaunchKernelGGL(fold_kernel, dim3(1), dim3(64), 0, s, dev, spread, b);
+    return (int)hipGetLastError();
+}

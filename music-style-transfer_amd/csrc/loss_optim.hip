@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
                                                        const float* il, const float* it, int ni,
                                                        const float* mlg, const float* mt, const float* bp, const float* bt,
                                                        const float* saved, const float* gl,
-                                                       float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb) {
+                                                       float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb, float info_scale) {
     __shared__ float coef[N_TAPE_IN];
     {
         const int64_t k = blockIdx.y;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
             }
         }
     } else {
-        const float ci = coef[13], cm = coef[14], cb = coef[15];
+        const float ci = coef[13] * info_scale, cm = coef[14] * info_scale, cb = coef[15] * info_scale;
         // d tanh already folded into coef (the tape's inputs are the raw losses)
         for (int j = threadIdx.x; j < ni; j += 256) gi[j] = ci * (1.f / (1.f + expf(-il[j])) - it[j]) / (float)ni;
         if (threadIdx.x == 0) {
@@ -330,16 +330,36 @@ int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* 
 int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
                      const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
-                     hipStream_t s) {
+                     hipStream_t s, float info_scale) {
     if (!pp || !pt || !saved || !gl || !gp || !gi || !gm || !gb || np <= 0 || lb.clips < 1) return MST_ERR_ARG;
     const int has_u = (up && ut && gu && nu > 0) ? 1 : 0;
     const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(nbp + nbu + 1, lb.clips), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
-                       has_u ? nu : (int64_t)0, nbu, il, it, ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb, lb);
+                       has_u ? nu : (int64_t)0, nbu, il, it, ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb, lb, info_scale);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
 static const LossBatch ONE_CLIP = {1, 0, 0, 0, 0, 0};
+
+int loss_blocks(int64_t n) { return blocks_for(n); }
+
+int loss_fwd_partials(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, float* scratch,
+                      hipStream_t s) {
+    const int has_u = (up && ut && nu > 0) ? 1 : 0;
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipLaunchKernelGGL(loss_partials_kernel, dim3(nbp + nbu, 1), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
+                       has_u ? nu : (int64_t)0, nbu, scratch, ONE_CLIP);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
+
+int loss_fwd_tail(int64_t np, int64_t nu, int has_u, const float* il, const float* it, int ni, const float* mlg, const float* mt,
+                  const float* bp, const float* bt, int normalize, float* losses, float* saved, float* scratch, hipStream_t s,
+                  float* gl_onehot, float* losses_out) {
+    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1, 1), dim3(64), 0, s, (const float*)scratch, nbp, nbu, has_u, il, it,
+                       ni, mlg, mt, bp, bt, normalize, losses, saved, ONE_CLIP, gl_onehot, losses_out);
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
 
 extern "C" int32_t mst_total_loss_fwd(const float* pp, const float* pt, int64_t np, const float* up, const float* ut,
                                       int64_t nu, const float* il, const float* it, int32_t ni, const float* mlg,

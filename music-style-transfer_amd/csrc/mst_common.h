@@ -188,6 +188,19 @@ struct RowLinDesc {
     int32_t first;               // backward: 1 = first writer of dx in this pass: store instead of +=
 };
 
+// ---- bar tiling of one clip over several ranks (mst_plan_options.tile_rows > 0, plan.hip "tiled") ----------------
+// strided row copy: dst[a * dst_sa + b * dst_sb + j] = src[a * src_sa + b * src_sb + j], j < cols (forward, activations);
+// backward: g_src (+)= g_dst over the same index map
+struct CopyDesc { int64_t src_off, dst_off; int32_t na, nb, cols, src_sa, src_sb, dst_sa, dst_sb, first; };
+// fold: sum[c] = sum over rows of part[row * row_stride + c * col_stride] (ordered) — the rank-local partial sums of a
+// global reduction; the host all-reduces `sum` over the ranks; spread writes it back as row 0 of the partials (other rows 0)
+// so that the unchanged consumer kernel re-sums exactly the global value
+struct FoldDesc { int32_t space, nrows, row_stride, ncols, col_stride, pad; int64_t part_off, sum_off /* SP_TMP */; };
+int launch_copy_rows(const CopyDesc* dev, const CopyDesc& host, int backward, Bases b, hipStream_t s);
+int launch_fold(const FoldDesc* dev, int spread, Bases b, hipStream_t s);
+// one half of a two-launch combine: which = 0 sums of squares, 1 apply, 2 backward reduce, 3 backward apply
+int launch_combine_phase(const CombineDesc* dev, int nblk, int which, Bases b, hipStream_t s);
+
 // ---- deferred weight-gradient reduction: gpar[dst+i] += sum_s ws[src + s*stride + i]
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
 // width > 0: the entry is a (count / width) x width block of a wider parameter matrix: element i lands at
@@ -239,6 +252,13 @@ int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count,
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 // per-clip strides of a batched loss evaluation (all 0 for the stand-alone single-clip entry points)
 struct LossBatch { int32_t clips; int64_t ws, grad, tmp, ext0, ext1; };
+// the two halves of loss_fwd_batched for tiled plans: partial sums, then (after the ranks' sums met) tail
+int loss_fwd_partials(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, float* scratch,
+                      hipStream_t s);
+int loss_fwd_tail(int64_t np, int64_t nu, int has_u, const float* il, const float* it, int ni, const float* mlg, const float* mt,
+                  const float* bp, const float* bt, int normalize, float* losses, float* saved, float* scratch, hipStream_t s,
+                  float* gl_onehot, float* losses_out);
+int loss_blocks(int64_t n);
 int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt, int normalize,
                      float* losses, float* saved, float* scratch, LossBatch lb, hipStream_t s,
@@ -247,7 +267,8 @@ int loss_fwd_batched(const float* pp, const float* pt, int64_t np, const float* 
 int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* up, const float* ut, int64_t nu, const float* il,
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
                      const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
-                     hipStream_t s);
+                     hipStream_t s, float info_scale = 1.f /* 0 on the non-root ranks of a tiled plan: the song-info gradients are
+                                                              replicated, only one rank may contribute them to the summed gradient */);
 bool rowlin_supported(int kin, int nout);
 int launch_rowlin_fwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);
 int launch_rowlin_bwd(const RowLinDesc* dev, const RowLinDesc& host, int count, Bases b, hipStream_t s);

@@ -194,7 +194,9 @@ extern "C" int32_t mst_param_info(const mst_dims* d, int32_t i, char* name, int3
 struct T { int64_t off; int rows, cols, ld; };
 struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
 enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B,
-       K_ME_SQ, K_ME_RED };
+       K_ME_SQ, K_ME_RED,
+       // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
+       K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG };
 struct Step { int kind, first, count, a, b, stage; };
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
@@ -228,8 +230,20 @@ struct mst_plan {
     mst_plan_options opt{};       // as given to mst_plan_create_ex (zeros = defaults)
     int mfma = 0;                 // GEMM tiling of this plan: 1 = 64x64 tiles (batched, FLOP-bound plans), 0 = 32x32 split-K tiles (latency)
 
-    int P() const { return d.C * d.R * d.T; }
-    int Q() const { return d.R * d.T; }
+    // bar tiling (mst_plan_options.tile_rows > 0): this rank owns bars [tile_r0, tile_r0 + tile_rows) of the d.R bars
+    bool tiled() const { return opt.tile_rows > 0; }
+    int Rl() const { return tiled() ? opt.tile_rows : d.R; }
+    int P() const { return d.C * Rl() * d.T; }          // positions / beats this plan computes (all of them when not tiled)
+    int Q() const { return Rl() * d.T; }
+    struct Xchg { int space; int64_t off; int32_t len; };
+    std::vector<CopyDesc> copies; std::vector<FoldDesc> folds; std::vector<Xchg> xchgs;
+    CopyDesc* d_copies = nullptr; FoldDesc* d_folds = nullptr;
+    std::vector<ZeroChunk> zero_fwd; ZeroChunk* d_zero_fwd = nullptr;      // activation ranges cleared before a tiled forward
+    int64_t loss_sum_off = 0;                                               // [SP_TMP] 16 floats: the loss partial sums, folded
+    int loss_fold[2] = {-1, -1};
+    // one train iteration of a tiled plan as phases: each runs launch steps and ends at an exchange (or at the end)
+    struct Phase { int what; int pass; int begin, end; int xchg; };        // what: 0 schedule steps, 1 loss partials, 2 loss tail + seed
+    std::vector<Phase> phases;
     int K() const { return d.clips > 1 ? d.clips : 1; }
     int64_t ext0_stride() const { return (int64_t)P() * NF * NPN * NPF; }
     int64_t ext1_stride() const { return (int64_t)Q() * NF * NUN * NUF; }
@@ -606,7 +620,39 @@ struct mst_plan {
         ops.push_back(op);
     }
 
-    void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out) {
+    // tiled: the exchange of one workspace range over the ranks (all-reduce SUM, done by the host between two phases).
+    // forward = the activation range, backward = the same range of the gradient arena (bwd_too), or a scratch range
+    void exchange(Op& op, int space, int64_t off, int len, bool bwd_too) {
+        op.fwd.push_back(Step{K_XCHG, (int)xchgs.size(), 1, 0, 0});
+        xchgs.push_back(Xchg{space, off, len});
+        if (space == SP_WS)          // the other ranks' rows must be zero when the SUM runs
+            for (int64_t at = off; at < off + len; at += 16384) zero_fwd.push_back(ZeroChunk{at, (int32_t)std::min<int64_t>(16384, off + len - at), 0});
+        if (bwd_too) { op.bwd.insert(op.bwd.begin(), Step{K_XCHG, (int)xchgs.size(), 1, 0, 0}); xchgs.push_back(Xchg{SP_GRAD, off, len}); }
+    }
+    // tiled: this rank's rows of a per-bar tensor into their place in a buffer that holds every rank's rows (the others'
+    // rows are zero, so that the exchange's SUM is an all-gather); backward: gather the owned rows' gradient back
+    void copy_rows(Op& op, int64_t src_off, int src_sa, int src_sb, int64_t dst_off, int dst_sa, int dst_sb, int na, int nb, int cols) {
+        CopyDesc c{}; c.src_off = src_off; c.dst_off = dst_off; c.na = na; c.nb = nb; c.cols = cols;
+        c.src_sa = src_sa; c.src_sb = src_sb; c.dst_sa = dst_sa; c.dst_sb = dst_sb;
+        op.fwd.insert(op.fwd.begin(), Step{K_COPY_F, (int)copies.size(), 1, 0, 0});
+        op.bwd.push_back(Step{K_COPY_B, (int)copies.size(), 1, 0, 0});
+        copies.push_back(c);
+    }
+    // tiled: rank-local partial sums -> `sum` (exchanged) -> back as the only non-zero partial
+    void fold_exchange(std::vector<Step>& steps, size_t at, int space, int64_t part_off, int nrows, int row_stride, int ncols,
+                       int col_stride) {
+        FoldDesc f{}; f.space = space; f.part_off = part_off; f.nrows = nrows; f.row_stride = row_stride; f.ncols = ncols;
+        f.col_stride = col_stride; f.sum_off = tmp(ncols);
+        const int fi = (int)folds.size();
+        folds.push_back(f);
+        const int xi = (int)xchgs.size();
+        xchgs.push_back(Xchg{SP_TMP, f.sum_off, ncols});
+        std::vector<Step> ins = {Step{K_FOLD, fi, 1, 0, 0}, Step{K_XCHG, xi, 1, 0, 0}, Step{K_SPREAD, fi, 1, 0, 0}};
+        steps.insert(steps.begin() + at, ins.begin(), ins.end());
+    }
+
+    // global = true (tiled plans): the slices hold this rank's rows only, the norms are over every rank's rows
+    void combine(int stage, int64_t x_off, int rows, int cols, int ld, int64_t cs, int Cn, const T& out, bool global = false) {
         CombineDesc c{}; c.Cn = Cn; c.rows = rows; c.cols = cols; c.ld = ld; c.x_off = x_off; c.cs = cs; c.out_off = out.off;
         c.stats_off = tmp(64); c.part_off = tmp(COMBINE_MAXBLK * (COMBINE_MAXC + 1));
         c.gx_off = x_off; c.gout_off = out.off;
@@ -615,8 +661,16 @@ struct mst_plan {
         c.nblk = (int)(nb < 1 ? 1 : (nb > COMBINE_MAXBLK ? COMBINE_MAXBLK : nb));
         const int large = (int64_t)rows * cols > COMBINE_SMALL ? 1 : 0;     // Step.b: 1 = needs the two-launch path
         Op op; op.stage = stage;
-        op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, c.nblk, large});
-        op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, c.nblk, large});
+        if (global && tiled()) {
+            const int ci = (int)combines.size();
+            op.fwd = {Step{K_COMB_F1, ci, 1, c.nblk, 0}, Step{K_COMB_F2, ci, 1, c.nblk, 0}};
+            fold_exchange(op.fwd, 1, SP_TMP, c.part_off, c.nblk, COMBINE_MAXC + 1, Cn, 1);
+            op.bwd = {Step{K_COMB_B1, ci, 1, c.nblk, 0}, Step{K_COMB_B2, ci, 1, c.nblk, 0}};
+            fold_exchange(op.bwd, 1, SP_TMP, c.part_off, c.nblk, COMBINE_MAXC + 1, Cn + 1, 1);
+        } else {
+            op.fwd.push_back(Step{K_COMB_F, (int)combines.size(), 1, c.nblk, large});
+            op.bwd.push_back(Step{K_COMB_B, (int)combines.size(), 1, c.nblk, large});
+        }
         combines.push_back(c);
         ops.push_back(op);
     }
@@ -632,7 +686,10 @@ struct mst_plan {
 static const int RS1[4] = {1, 1, 1, 1};
 
 void mst_plan::build() {
-    const int C = d.C, R = d.R, Tn = d.T, P_ = P(), Q_ = Q();
+    // R = the bars this plan computes per-position work for (its tile when tiled), Rt = the clip's bars: the bar-level chains
+    // (bars LSTMs, style encoder, song-info bars LSTM) run replicated over all Rt bars on every rank
+    const int C = d.C, R = Rl(), Rt = d.R, r0 = tiled() ? opt.tile_r0 : 0, Tn = d.T, P_ = P(), Q_ = Q();
+    const bool TL = tiled();
     const bool U = d.has_unpitched != 0;
     const int E = MST_STAGE_EXTRACT, IN = MST_STAGE_INFO, AP = MST_STAGE_APPLY;
     // ---- inputs / targets (never zeroed, written by the host side)
@@ -662,26 +719,42 @@ void mst_plan::build() {
         beat_group.push_back(LstmSpec{ua, R, Tn, z.H, 0, mu + ".beats_lstm.module", ubeats, 0});
     }
     lstm_group(E, beat_group);
-    T plast = newT(R, z.H), ulast{};
-    combine(E, pbeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, (int64_t)R * Tn * z.H, C, plast);
-    T pbars = newT(R, 2 * z.HB, "pitched_bars"), ubars{};
-    std::vector<LstmSpec> bar_group = {LstmSpec{plast, 1, R, z.HB, 0, m + ".bars_lstm", pbars, 0},
-                                       LstmSpec{plast, 1, R, z.HB, 1, m + ".bars_lstm", pbars, z.HB}};
+    T plast = newT(Rt, z.H), ulast{};
+    T pbl_all{}, ubl_all{};
+    if (TL) {
+        // last-beat states of every rank's bars, bar-major [(bar, channel), H] | [bar, H]: own rows copied in, one exchange
+        pbl_all = newT(Rt * C, z.H);
+        if (U) ubl_all = newT(Rt, z.H);
+        Op op; op.stage = E;
+        exchange(op, SP_WS, pbl_all.off, (int)((U ? ubl_all.off + (int64_t)Rt * z.H : pbl_all.off + (int64_t)Rt * C * z.H) - pbl_all.off), true);
+        copy_rows(op, pbeats.off + (int64_t)(Tn - 1) * z.H, Tn * z.H, R * Tn * z.H, pbl_all.off + (int64_t)r0 * C * z.H, C * z.H, z.H, R, C, z.H);
+        if (U) copy_rows(op, ubeats.off + (int64_t)(Tn - 1) * z.H, Tn * z.H, 0, ubl_all.off + (int64_t)r0 * z.H, z.H, 0, R, 1, z.H);
+        ops.push_back(op);
+        combine(E, pbl_all.off, Rt, z.H, C * z.H, z.H, C, plast);
+    } else
+        combine(E, pbeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, (int64_t)R * Tn * z.H, C, plast);
+    T pbars = newT(Rt, 2 * z.HB, "pitched_bars"), ubars{};
+    std::vector<LstmSpec> bar_group = {LstmSpec{plast, 1, Rt, z.HB, 0, m + ".bars_lstm", pbars, 0},
+                                       LstmSpec{plast, 1, Rt, z.HB, 1, m + ".bars_lstm", pbars, z.HB}};
     if (U) {
-        ulast = newT(R, z.H);
-        combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
-        ubars = newT(R, 2 * z.HB, "unpitched_bars");
-        bar_group.push_back(LstmSpec{ulast, 1, R, z.HB, 0, mu + ".bars_lstm", ubars, 0});
-        bar_group.push_back(LstmSpec{ulast, 1, R, z.HB, 1, mu + ".bars_lstm", ubars, z.HB});
+        ulast = newT(Rt, z.H);
+        if (TL) combine(E, ubl_all.off, Rt, z.H, z.H, 0, 1, ulast);
+        else combine(E, ubeats.off + (int64_t)(Tn - 1) * z.H, R, z.H, Tn * z.H, 0, 1, ulast);
+        ubars = newT(Rt, 2 * z.HB, "unpitched_bars");
+        bar_group.push_back(LstmSpec{ulast, 1, Rt, z.HB, 0, mu + ".bars_lstm", ubars, 0});
+        bar_group.push_back(LstmSpec{ulast, 1, Rt, z.HB, 1, mu + ".bars_lstm", ubars, z.HB});
     }
     lstm_group(E, bar_group);
+    // this rank's bars of the (replicated) bar tensors
+    const T pbars_own{pbars.off + (int64_t)r0 * pbars.ld, R, pbars.cols, pbars.ld};
+    const T ubars_own = U ? T{ubars.off + (int64_t)r0 * ubars.ld, R, ubars.cols, ubars.ld} : T{};
 
     m = "pitched_rhythm_encoder";
     T pre_il = linear(E, instr, false, m + ".instruments_linear", z.PRE_IL, ACT_LEAKY);
     T pre_ml = linear(E, mode, false, m + ".mode_linear", z.PRE_ML, ACT_LEAKY);
     T pre_bp = linear(E, bpm, false, m + ".bpm_linear", z.PRE_BPL, ACT_LEAKY);
     T pre_bl = linear(E, pbeats, true, m + ".beats_linear", z.PRE_BL, ACT_LEAKY);
-    T pre_br = linear(E, pbars, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
+    T pre_br = linear(E, pbars_own, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
     T pre_cl = linear(E, SP_EXT0, 0, NPN * NPF, P_ * NF, NPN * NPF, false, m + ".channels_linear.weight",
                       m + ".channels_linear.bias", z.PRE_CL, ACT_LEAKY);
     const int rsCRTF[4] = {C, R, Tn, NF};
@@ -690,26 +763,26 @@ void mst_plan::build() {
                       seg(pre_il, 1, 0, 0, 0), seg0(pre_ml), seg0(pre_bp)});
     T prh_c = linear(E, prcat, true, m + ".linear", z.RH, ACT_LEAKY);
     T prh = newT(Q_ * NF, z.RH, "pitched_rhythm");
-    combine(E, prh_c.off, Q_ * NF, z.RH, z.RH, (int64_t)Q_ * NF * z.RH, C, prh);
+    combine(E, prh_c.off, Q_ * NF, z.RH, z.RH, (int64_t)Q_ * NF * z.RH, C, prh, true);
 
     T bars = pbars, rhythm = prh;
     if (U) {
         m = "unpitched_rhythm_encoder";
         T ure_bp = linear(E, bpm, false, m + ".bpm_linear", z.PRE_BPL, ACT_LEAKY);
         T ure_bl = linear(E, ubeats, true, m + ".beats_linear", z.PRE_BL, ACT_LEAKY);
-        T ure_br = linear(E, ubars, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
+        T ure_br = linear(E, ubars_own, true, m + ".bars_linear", z.PRE_BRL, ACT_LEAKY);
         T ure_cl = linear(E, SP_EXT1, 0, NUN * NUF, Q_ * NF, NUN * NUF, false, m + ".channels_linear.weight",
                           m + ".channels_linear.bias", z.URE_CL, ACT_LEAKY);
         const int rs1RTF[4] = {1, R, Tn, NF};
         T urcat = gather(E, rs1RTF, {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp)});
         T urh_c = linear(E, urcat, true, m + ".linear", z.RH, ACT_LEAKY);
         T urh = newT(Q_ * NF, z.RH, "unpitched_rhythm");
-        combine(E, urh_c.off, Q_ * NF, z.RH, z.RH, 0, 1, urh);
+        combine(E, urh_c.off, Q_ * NF, z.RH, z.RH, 0, 1, urh, true);
         // combine(pitched, unpitched) stacks the pair on a new leading axis (style/model.py:766-767)
-        bars = newT(R, z.BAR, "bars");
-        combine(E, pbars.off, R, z.BAR, z.BAR, ubars.off - pbars.off, 2, bars);
+        bars = newT(Rt, z.BAR, "bars");
+        combine(E, pbars.off, Rt, z.BAR, z.BAR, ubars.off - pbars.off, 2, bars);
         rhythm = newT(Q_ * NF, z.RH, "rhythm");
-        combine(E, prh.off, Q_ * NF, z.RH, z.RH, urh.off - prh.off, 2, rhythm);
+        combine(E, prh.off, Q_ * NF, z.RH, z.RH, urh.off - prh.off, 2, rhythm, true);
     } else {
         named["bars"] = bars; named["rhythm"] = rhythm;
     }
@@ -718,9 +791,9 @@ void mst_plan::build() {
     T se_il = linear(E, instr, false, m + ".instruments_linear", z.SE_IL, ACT_LEAKY);
     T se_ml = linear(E, mode, false, m + ".mode_linear", z.SE_ML, ACT_LEAKY);
     T se_bp = linear(E, bpm, false, m + ".bpm_linear", z.SE_BL, ACT_LEAKY);
-    T sel = newT(R, z.SE_L);
-    lstm(E, bars, 1, R, z.SE_L, 0, m + ".bars_lstm", sel, 0);
-    T sel_last{sel.off + (int64_t)(R - 1) * z.SE_L, 1, z.SE_L, z.SE_L};
+    T sel = newT(Rt, z.SE_L);
+    lstm(E, bars, 1, Rt, z.SE_L, 0, m + ".bars_lstm", sel, 0);
+    T sel_last{sel.off + (int64_t)(Rt - 1) * z.SE_L, 1, z.SE_L, z.SE_L};
     const int rsC[4] = {C, 1, 1, 1};
     T secat = gather(E, rsC, {seg0(sel_last), seg(se_il, 1, 0, 0, 0), seg0(se_ml), seg0(se_bp)});
     T se_lin = linear(E, secat, true, m + ".linear", z.STYLE, ACT_LEAKY);
@@ -730,7 +803,7 @@ void mst_plan::build() {
     m = "melody_encoder";
     T me_il = linear(E, instr, false, m + ".instruments_linear", z.ME_IL, ACT_LEAKY);
     T me_bl = linear(E, pbeats, true, m + ".beats_linear", z.ME_BL, ACT_LEAKY);
-    T me_br = linear(E, pbars, true, m + ".bars_linear", z.ME_BRL, ACT_LEAKY);
+    T me_br = linear(E, pbars_own, true, m + ".bars_linear", z.ME_BRL, ACT_LEAKY);
     const int rsCRT[4] = {C, R, Tn, 1};
     T ycat = gather(E, rsCRT, {seg(me_bl, R * Tn, Tn, 1, 0), seg(me_br, 0, 1, 0, 0), seg(me_il, 1, 0, 0, 0)});
     T me_oct = linear(E, ycat, true, m + ".octave_linear", z.MEL * NOCT, ACT_LEAKY);
@@ -759,6 +832,10 @@ void mst_plan::build() {
         op.fwd.push_back(Step{K_ME_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_RED, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_ME_B, (int)notes.size(), 1, 0, 0});
+        if (TL) {      // the channel norms are over every rank's positions
+            fold_exchange(op.fwd, 1, SP_TMP, n.part_off, n.nwc, 1, C, n.nwc);
+            fold_exchange(op.bwd, 1, SP_TMP, n.part_off, n.nwc, 1, C + 1, n.nwc);
+        }
         notes.push_back(n); ops.push_back(op);
         // channels_linear.{weight,bias}, linear.{weight,bias} are contiguous in the flat buffer
         slabs[0].push_back(SlabEntry{n.wc_off, n.slab_off, nw, nw, n.nblk});
@@ -772,9 +849,17 @@ void mst_plan::build() {
     T sbl = newT(Q_, z.SIM_BL);
     lstm(IN, rhy_rows, R, Tn, z.SIM_BL, 0, m + ".beats_lstm.module", sbl, 0);
     T slast{sbl.off + (int64_t)(Tn - 1) * z.SIM_BL, R, z.SIM_BL, Tn * z.SIM_BL};
-    T sbr = newT(R, z.NRF);
-    lstm(IN, slast, 1, R, z.NRF, 0, m + ".bars_lstm", sbr, 0);
-    T feats{sbr.off + (int64_t)(R - 1) * z.NRF, 1, z.NRF, z.NRF};
+    if (TL) {          // every rank's last-beat rhythm features, then the bars LSTM replicated
+        T sl_all = newT(Rt, z.SIM_BL);
+        Op op; op.stage = IN;
+        exchange(op, SP_WS, sl_all.off, Rt * z.SIM_BL, true);
+        copy_rows(op, slast.off, Tn * z.SIM_BL, 0, sl_all.off + (int64_t)r0 * z.SIM_BL, z.SIM_BL, 0, R, 1, z.SIM_BL);
+        ops.push_back(op);
+        slast = sl_all;
+    }
+    T sbr = newT(Rt, z.NRF);
+    lstm(IN, slast, 1, Rt, z.NRF, 0, m + ".bars_lstm", sbr, 0);
+    T feats{sbr.off + (int64_t)(Rt - 1) * z.NRF, 1, z.NRF, z.NRF};
     struct Head { const char* nm; int sw, rw, n, act; const char* out; };
     const Head heads[3] = {{"instruments", z.SIM_SI, z.SIM_RI, z.NI, ACT_NONE, "instruments_pred"},
                            {"mode", z.SIM_SM, z.SIM_RM, 2, ACT_NONE, "mode_pred"},
@@ -973,6 +1058,45 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             }
             break;
         }
+        case K_COMB_F1: case K_COMB_F2: case K_COMB_B1: case K_COMB_B2: {
+            const CombineDesc& c = combines[s.first + i];
+            const int64_t span = (int64_t)(c.Cn - 1) * (c.cs < 0 ? -c.cs : c.cs) + (int64_t)(c.rows - 1) * c.ld + c.cols;
+            const int64_t lo = c.cs < 0 ? c.x_off + (int64_t)(c.Cn - 1) * c.cs : c.x_off;
+            const int64_t n = (int64_t)c.rows * c.cols;
+            acc_add(v, SP_WS, lo, span, false);
+            const bool part_w = s.kind == K_COMB_F1 || s.kind == K_COMB_B1;
+            acc_add(v, SP_TMP, c.part_off, COMBINE_MAXBLK * (COMBINE_MAXC + 1), part_w);
+            if (s.kind == K_COMB_F2) { acc_add(v, SP_WS, c.out_off, n, true); acc_add(v, SP_TMP, c.stats_off, 64, true); }
+            if (s.kind == K_COMB_B1 || s.kind == K_COMB_B2) {
+                acc_add(v, SP_WS, c.out_off, n, false);
+                acc_add(v, SP_GRAD, c.gout_off, n, false);
+            }
+            if (s.kind == K_COMB_B2) {
+                acc_add(v, SP_TMP, c.stats_off, 64, false);
+                acc_add(v, SP_GRAD, lo - c.x_off + c.gx_off, span, true, true, span == (int64_t)c.Cn * n);
+            }
+            break;
+        }
+        case K_COPY_F: case K_COPY_B: {
+            const CopyDesc& c = copies[s.first + i];
+            const int64_t ss = (int64_t)(c.na - 1) * c.src_sa + (int64_t)(c.nb - 1) * c.src_sb + c.cols;
+            const int64_t ds = (int64_t)(c.na - 1) * c.dst_sa + (int64_t)(c.nb - 1) * c.dst_sb + c.cols;
+            if (s.kind == K_COPY_F) { acc_add(v, SP_WS, c.src_off, ss, false); acc_add(v, SP_WS, c.dst_off, ds, true); }
+            else { acc_add(v, SP_GRAD, c.dst_off, ds, false); acc_add(v, SP_GRAD, c.src_off, ss, true, true, false); }
+            break;
+        }
+        case K_FOLD: case K_SPREAD: {
+            const FoldDesc& f = folds[s.first + i];
+            const int64_t span = (int64_t)(f.nrows - 1) * f.row_stride + (int64_t)(f.ncols - 1) * f.col_stride + 1;
+            acc_add(v, f.space, f.part_off, span, s.kind == K_SPREAD);
+            acc_add(v, SP_TMP, f.sum_off, f.ncols, s.kind == K_FOLD);
+            break;
+        }
+        case K_XCHG: {
+            const Xchg& x = xchgs[s.first + i];
+            acc_add(v, x.space, x.off, x.len, true);
+            break;
+        }
         case K_ROW_F: case K_ROW_B: {
             const RowLinDesc& r = rowlins[s.first + i];
             const int64_t nx = (int64_t)r.rows * r.kin, ny = (int64_t)r.rows * r.nout;
@@ -1063,7 +1187,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                                    s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
             Step m = s0; m.count = 0;
             const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
-            const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B;
+            const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B || (s0.kind >= K_COMB_F1 && s0.kind <= K_COMB_B2);
             const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B || s0.kind == K_ME_SQ || s0.kind == K_ME_RED;
             if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
             else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
@@ -1170,11 +1294,12 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
     const int copies = K();
     for (size_t si = begin; si < list.size(); ++si) {
         Step& m = list[si];
-        const int nm = m.kind == K_GEMM ? m.b : m.count / copies;
+        const bool plain = m.kind >= K_COPY_F;               // indexes an unscheduled (one-clip) descriptor vector
+        const int nm = m.kind == K_GEMM ? m.b : (plain ? m.count : m.count / copies);
         for (int q = 0; q < nm; ++q) {
             std::vector<Acc> acc;
             Step one = m; one.first = m.first + q; one.count = 1;
-            accesses(one, acc, true);
+            accesses(one, acc, !plain);
             for (const Acc& a : acc) {
                 if (a.space != SP_GRAD || a.w) continue;
                 if (!covered(have, a.lo, a.hi)) { Acc z = a; z.w = true; z.space = m.stage; zero.push_back(z); have.push_back(a); }
@@ -1186,11 +1311,12 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
                 if (a.dense && !touches(have, a.lo, a.hi)) { first = 1; have.push_back(a); }
                 else if (!covered(have, a.lo, a.hi)) { Acc z = a; z.space = m.stage; zero.push_back(z); have.push_back(a); }
             }
-            for (int k = 0; k < copies; ++k) {
+            if (m.kind == K_COPY_B) this->copies[m.first + q].first = first;
+            for (int k = 0; k < copies && !plain; ++k) {
                 const int idx = m.first + k * nm + q;
                 if (m.kind == K_GEMM) s_gemms[idx].out.first = first;
                 else if (m.kind == K_SEGRED) s_segreds[idx].first = first;
-                else if (m.kind == K_COMB_B) s_combines[idx].first = first;
+                else if (m.kind == K_COMB_B || m.kind == K_COMB_B2) s_combines[idx].first = first;
                 else if (m.kind == K_ROW_B) s_rowlins[idx].first = first;
             }
         }
@@ -1222,6 +1348,31 @@ void mst_plan::schedule() {
     };
     for (int st = 0; st < 3; ++st) chunks(zs, 1 << st, zero_stage[st]);
     chunks(za, MST_STAGE_ALL, zero_all);
+    if (!tiled()) return;
+    // ---- one train iteration of a tiled plan as phases that end at an exchange
+    {   // loss partial sums (7 per note tensor, one row per workgroup) -> 16 floats that the ranks sum
+        const bool U = d.has_unpitched != 0;
+        loss_sum_off = tmp(16);
+        const int64_t np = (int64_t)P() * NF * NPN, nu = U ? (int64_t)Q() * NF * NUN : 0;
+        FoldDesc f{}; f.space = SP_TMP; f.part_off = loss_scratch; f.nrows = loss_blocks(np); f.row_stride = 8; f.ncols = 7; f.col_stride = 1;
+        f.sum_off = loss_sum_off;
+        loss_fold[0] = (int)folds.size(); folds.push_back(f);
+        f.part_off = loss_scratch + (mst_loss_scratch_floats() - 64) / 2; f.nrows = U ? loss_blocks(nu) : 1; f.sum_off = loss_sum_off + 8;
+        loss_fold[1] = (int)folds.size(); folds.push_back(f);
+    }
+    auto split = [&](int pass) {
+        const std::vector<Step>& L = sched_all[pass];
+        int begin = 0;
+        for (int i = 0; i < (int)L.size(); ++i)
+            if (L[i].kind == K_XCHG) { phases.push_back(Phase{0, pass, begin, i, L[i].first}); begin = i + 1; }
+        phases.push_back(Phase{0, pass, begin, (int)L.size(), -1});
+    };
+    split(0);
+    const int lx = (int)xchgs.size();
+    xchgs.push_back(Xchg{SP_TMP, loss_sum_off, 16});
+    phases.push_back(Phase{1, 0, 0, 0, lx});
+    phases.push_back(Phase{2, 0, 0, 0, -1});
+    split(1);
 }
 
 template <class D>
@@ -1240,6 +1391,7 @@ int mst_plan::upload() {
     s_gemm_starts.resize(s_gemms.size());
     for (size_t i = 0; i < s_gemms.size(); ++i) s_gemm_starts[i] = s_gemms[i].blk_begin;
     e |= up(s_gemm_starts, &d_gemm_starts);
+    e |= up(copies, &d_copies); e |= up(folds, &d_folds); e |= up(zero_fwd, &d_zero_fwd);
     for (int st = 0; st < 3; ++st) e |= up(zero_stage[st], &d_zero_stage[st]);
     e |= up(zero_all, &d_zero_all);
     for (int s = 0; s < 3; ++s) {
@@ -1266,6 +1418,9 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && ((opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64) || opt->gemm_run < 0 || opt->gemm_run > 64)) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && (opt->tile_rows < 0 || opt->tile_r0 < 0 || (opt->tile_rows > 0 && (opt->tile_r0 + opt->tile_rows > d->R || d->clips > 1)))) {
+        *status = MST_ERR_ARG; return nullptr;
+    }
     mst_plan* p = new mst_plan();
     if (opt) p->opt = *opt;
     p->d = *d; p->z = mst_sizes(*d);
@@ -1282,7 +1437,7 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
-    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins); hipFree(p->d_zero_all);
+    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins); hipFree(p->d_zero_all); hipFree(p->d_copies); hipFree(p->d_folds); hipFree(p->d_zero_fwd);
     for (int st = 0; st < 3; ++st) hipFree(p->d_zero_stage[st]);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
@@ -1339,6 +1494,15 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, p->s_lstms[s.first].multi, b, st);
     case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
     case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
+    case K_COMB_F1: return launch_combine_phase(p->d_combines + s.first, s.a, 0, b, st);
+    case K_COMB_F2: return launch_combine_phase(p->d_combines + s.first, s.a, 1, b, st);
+    case K_COMB_B1: return launch_combine_phase(p->d_combines + s.first, s.a, 2, b, st);
+    case K_COMB_B2: return launch_combine_phase(p->d_combines + s.first, s.a, 3, b, st);
+    case K_COPY_F: return launch_copy_rows(p->d_copies + s.first, p->copies[s.first], 0, b, st);
+    case K_COPY_B: return launch_copy_rows(p->d_copies + s.first, p->copies[s.first], 1, b, st);
+    case K_FOLD: return launch_fold(p->d_folds + s.first, 0, b, st);
+    case K_SPREAD: return launch_fold(p->d_folds + s.first, 1, b, st);
+    case K_XCHG: return MST_ERR_UNSUPPORTED;        // a tiled plan runs through mst_tiled_phase, which stops at exchanges
     case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ROW_B: return launch_rowlin_bwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ME_SQ: return launch_me_sumsq(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
@@ -1430,6 +1594,72 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
+
+// ------------------------------------------------------------------------------------------ tiled plans
+// One train iteration (train-model.py:113-126) of ONE long clip whose bars are tiled over several ranks (BASELINE.json
+// configs[4]).  Every rank builds a plan for its bar tile (mst_plan_options.tile_r0 / tile_rows) and walks the
+// same phase list; after a phase that reports xlen > 0 the host all-reduces (SUM) ws[xoff, xoff + xlen) over the ranks
+// before the next phase.  What crosses ranks: the last-beat states feeding the replicated bar-level LSTMs (an all-gather as a
+// SUM over zero-padded buffers), the partial sums of every global reduction (combine's per-channel sums of squares and its
+// backward's sum(g x), sum(g out); the loss sums) and, backward, the gradients of the gathered rows.  Everything else is local
+// or replicated; gradients of replicated operations computed from a rank's PARTIAL upstream gradient add up to the true
+// gradient in the final all-reduce of gparams because backward is linear in the upstream gradient — the song-info loss
+// gradients, which are complete on every rank, are therefore seeded on the root rank only.
+extern "C" int32_t mst_tiled_phase_count(const mst_plan* p) { return p ? (int32_t)p->phases.size() : MST_ERR_ARG; }
+
+extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float* params, float* gparams, float* ws,
+                                   const float* pitched, const float* unpitched, float* losses, int32_t is_root,
+                                   mst_stream stream, int64_t* xoff, int64_t* xlen) {
+    if (!p || !p->tiled() || phase < 0 || phase >= (int)p->phases.size() || !params || !gparams || !ws || !pitched || !xoff || !xlen)
+        return MST_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const mst_plan::Phase& ph = p->phases[phase];
+    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    const bool U = p->d.has_unpitched != 0;
+    float* g = ws + p->act_top;
+    auto at = [&](const char* n) { return p->named.at(n).off; };
+    const int64_t np = (int64_t)p->P() * NF * NPN, nu = U ? (int64_t)p->Q() * NF * NUN : 0;
+    float* lscratch = ws + 2 * p->act_top + p->loss_scratch;
+    if (phase == 0) {
+        if (launch_zero(p->d_zero_all, (int)p->zero_all.size(), 1, g, p->act_top, st)) return MST_ERR_LAUNCH;
+        if (launch_zero(p->d_zero_fwd, (int)p->zero_fwd.size(), 1, ws, p->act_top, st)) return MST_ERR_LAUNCH;
+    }
+    if (ph.what == 0) {
+        const std::vector<Step>& L = p->sched_all[ph.pass];
+        for (int i = ph.begin; i < ph.end; ++i) {
+            int e = run_step(p, L[i], b, st);
+            if (e) return e < 0 ? e : MST_ERR_LAUNCH;
+        }
+        if (ph.pass == 1 && phase == (int)p->phases.size() - 1)
+            for (int s = 2; s >= 0; --s)
+                if (launch_slab_reduce(p->d_slabs[s], p->d_slab_blocks[s], (int)p->slab_blocks[s].size(), b, st)) return MST_ERR_LAUNCH;
+    } else if (ph.what == 1) {
+        int e = loss_fwd_partials(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr, nu,
+                                  lscratch, st);
+        if (e) return e;
+        if (launch_fold(p->d_folds + p->loss_fold[0], 0, b, st) || (U && launch_fold(p->d_folds + p->loss_fold[1], 0, b, st))) return MST_ERR_LAUNCH;
+    } else {
+        if (launch_fold(p->d_folds + p->loss_fold[0], 1, b, st) || (U && launch_fold(p->d_folds + p->loss_fold[1], 1, b, st))) return MST_ERR_LAUNCH;
+        int e = loss_fwd_tail(np, nu, U ? 1 : 0, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
+                              ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), 1, ws + p->t_losses.off, ws + p->t_saved.off,
+                              lscratch, st, ws + p->t_gl.off, losses);
+        if (e) return e;
+        const LossBatch lb = {1, 0, 0, 0, 0, 0};
+        e = loss_bwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr, nu,
+                             ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"), ws + at("mode"),
+                             ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off, ws + p->t_gl.off, g + at("pitched_pred"),
+                             U ? g + at("unpitched_pred") : nullptr, g + at("instruments_pred"), g + at("mode_pred"), g + at("bpm_pred"),
+                             lb, st, is_root ? 1.f : 0.f);
+        if (e) return e;
+    }
+    *xoff = 0; *xlen = 0;
+    if (ph.xchg >= 0) {
+        const mst_plan::Xchg& x = p->xchgs[ph.xchg];
+        const int64_t base = x.space == SP_WS ? 0 : (x.space == SP_GRAD ? p->act_top : 2 * p->act_top);
+        *xoff = base + x.off; *xlen = x.len;
+    }
+    return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
+}
 
 // ------------------------------------------------------------------------------------------ instrumentation
 // Per-launch-step timing with HIP events recorded on the caller's stream (bench.py's roofline leg).

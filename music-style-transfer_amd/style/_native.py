@@ -39,7 +39,8 @@ class Dims(C.Structure):
 
 
 class PlanOptions(C.Structure):
-    _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('reserved', C.c_int32 * 5)]
+    _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('tile_r0', C.c_int32),
+                ('tile_rows', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 def options_from_env():
@@ -77,6 +78,8 @@ _SIGS = {
     'mst_total_loss_bwd': (C.c_int32, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P,
                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     'mst_train_iteration': (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    'mst_tiled_phase_count': (C.c_int32, [_P]),
+    'mst_tiled_phase': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mst_adam_step': (C.c_int32, [_P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_int32, C.c_double, C.c_int32, _P]),
     'mst_adam_step2': (C.c_int32, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -159,12 +162,12 @@ class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
     WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
         env = options_from_env()
         opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
                            no_merge=env['no_merge'] if no_merge is None else int(no_merge),
-                           gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run))
+                           gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run), tile_r0=int(tile_r0), tile_rows=int(tile_rows))
         st = C.c_int32()
         self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:
@@ -252,6 +255,21 @@ class Plan:
         if got != n:
             check(got if got < 0 else -1, 'mst_plan_time_steps')
         return list(zip(kind.tolist(), ms.tolist(), fl.tolist(), by.tolist()))
+
+    def tiled_train_iteration(self, params, gparams, pitched, unpitched, losses=None, is_root=True, all_reduce=None):
+        """One loop body of a clip whose bars are tiled over ranks (plan made with tile_r0 / tile_rows; `pitched` /
+        `unpitched` hold this rank's bars only).  `all_reduce(tensor)` sums a workspace range over the ranks in place —
+        torch.distributed.all_reduce by default.  gparams receives this rank's share: all-reduce it before the optimizer step."""
+        if all_reduce is None:
+            import torch.distributed as dist
+            all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        xoff, xlen = C.c_int64(), C.c_int64()
+        for ph in range(self.lib.mst_tiled_phase_count(self.handle)):
+            check(self.lib.mst_tiled_phase(self.handle, ph, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched), ptr(unpitched),
+                                           ptr(losses), int(bool(is_root)), current_stream(self.device), C.byref(xoff), C.byref(xlen)),
+                  f'mst_tiled_phase({ph})')
+            if xlen.value:
+                all_reduce(self.ws[xoff.value:xoff.value + xlen.value])
 
     def train_iteration(self, params, gparams, pitched, unpitched, losses=None, ws=None):
         check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws if ws is None else ws),

@@ -81,3 +81,47 @@ def test_oracle_training_cap_shape(native):
     # the reference's own cap: songs are cut to 800 // C bars for training (train-model.py:101) => C=4, R=200, T=4
     e, worst = pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 200, 4, True, clip_id=11)
     print('training cap: all-gradient rel-L2', e, 'worst tensor', worst)
+
+
+def test_bar_tiling_two_tiles_bench_clip(native):
+    # the bench clip's 16 bars over two "ranks" (both plans on this GPU, exchanges summed by hand)
+    from test_tiled import run_tiled
+    from oracle import style_oracle as so
+    from oracle.synth import synth_clip
+    from simutil import make_dims, rel
+    from style import _native as nat
+    dev = torch.device('cuda:0')
+    C, R, T = 4, 16, 4
+    dims = make_dims(pc.FULL, C, R, T, True)
+    flat, named, table = pc.random_params(native, dims, 0)
+    clip = synth_clip(5, C, R, T, True)
+    gt, lt, plans, nx = run_tiled(native, dev, pc.FULL, C, R, T, True, [(0, 9), (9, 7)], clip, flat)
+    _, ref_losses = so.iteration(named, clip)
+    gref = torch.cat([(named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])).reshape(-1) for n, _, _ in table])
+    assert rel(gt.cpu().numpy(), gref.numpy()) < pc.TOL
+    for l in lt:
+        for i, k in enumerate(nat.LOSS_KEYS):
+            if k in ref_losses:
+                assert abs(float(l[i]) - ref_losses[k]) < 5e-5, k
+
+
+def test_bar_tiling_config5_shape_eight_tiles(native):
+    # BASELINE.json configs[4]: C=8, R=151 bars (5 min + 1), T=4, bars tiled 8 ways (19 bars per rank, 18 for the last);
+    # eight plans on this one GPU stand in for the eight ranks
+    from test_tiled import run_tiled
+    from oracle import style_oracle as so
+    from oracle.synth import synth_clip
+    from simutil import make_dims, rel
+    dev = torch.device('cuda:0')
+    C, R, T = 8, 151, 4
+    dims = make_dims(pc.FULL, C, R, T, True)
+    flat, named, table = pc.random_params(native, dims, 0)
+    clip = synth_clip(9, C, R, T, True)
+    tiles = [(19 * k, 19 if k < 7 else 18) for k in range(8)]
+    gt, lt, plans, nx = run_tiled(native, dev, pc.FULL, C, R, T, True, tiles, clip, flat)
+    _, ref_losses = so.iteration(named, clip)
+    gref = torch.cat([(named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])).reshape(-1) for n, _, _ in table])
+    e = rel(gt.cpu().numpy(), gref.numpy())
+    print('configs[4] shape, 8 tiles: all-gradient rel-L2', e, 'exchanges per iteration', nx)
+    assert e < pc.TOL
+    assert abs(float(lt[3][0]) - ref_losses['total']) < 5e-5
