@@ -200,6 +200,52 @@ def batched_leg(native, nat, dev, flat, K, passes, warm):
                 roofline=roof, kernel_breakdown=rows)
 
 
+def surface_leg(dev, clip, iters, warm):
+    """The drop-in path a user of the reference gets by changing the import (train-model.py:97-154 -> style/train.py): the
+    nn.Module surface — model(...) -> get_total_loss(...) -> losses['total'].backward() -> FusedAdam.step() every iter_size
+    iterations — on the bench clip, seed-108 weights, eager launches through torch.autograd (no hipGraph, the 15 loss leaves
+    stay on the device like in style/train.py)."""
+    import style.model as sm
+    from style.optim import FusedAdam
+    from style.train import build_model
+    model = build_model().to(dev)
+    opt = FusedAdam(model, lr=.01, step_size=200, gamma=.9)
+    c = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in clip.items()}
+
+    def body(it):
+        (ip, mp, bp), xp, xu = model(c['mode'], c['bpm'], c['pitched'], c['instruments_features'], c['unpitched'])
+        losses = sm.get_total_loss(ip, c['used_instruments'], bp, c['bpm_int'], mp, c['mode'], xp, c['pitched'], xu, c['unpitched'],
+                                   normalize=True)
+        losses['total'].backward()
+        if (it + 1) % ITER_SIZE == 0:
+            opt.step()
+        return losses.packed
+
+    def fused_body(it):      # style/train.py's default: the loop body as one C-ABI call (StyleTransferModel.train_iteration)
+        packed = model.train_iteration(c['mode'], c['bpm'], c['pitched'], c['instruments_features'], c['unpitched'],
+                                       c['used_instruments'], c['bpm_int'])
+        if (it + 1) % ITER_SIZE == 0:
+            opt.step()
+        return packed
+
+    def timed(fn):
+        for it in range(warm):
+            fn(it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(iters):
+            packed = fn(it)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, packed
+
+    dt_f, _ = timed(fused_body)
+    dt, packed = timed(body)
+    return dict(value=iters / dt, fused_value=iters / dt_f, fused_ms_per_step=dt_f / iters * 1e3, unit='iters/s', ms_per_step=dt / iters * 1e3, steps=iters, warmup=warm,
+                config=dict(workload='the same clip through the reference\'s Python surface (style.model.StyleTransferModel.forward, '
+                                     'get_total_loss, autograd backward, FusedAdam every 2nd iteration), eager, no hipGraph',
+                            final_total_loss=float(packed.cpu()[0])))
+
+
 LONG_CLIP = dict(C=8, R=151, T=4)       # BASELINE.json configs[4] mapped per SURVEY.md 8(d): 5 min at 120 bpm + 1 = 151 bars, 8 channels
 
 
@@ -280,6 +326,9 @@ def main():
                     help='with the default one-clip workload on 1 GPU: also time this many clips in one batched plan (configs[2]) for '
                          'a few passes and report it as "batched" in the same JSON line; 0 = skip')
     ap.add_argument('--batched-passes', type=int, default=12)
+    ap.add_argument('--surface-steps', type=int, default=200,
+                    help='with the default workload on 1 GPU: also time this many loop bodies through the nn.Module surface '
+                         '(the drop-in path behind train-model.py) and report them as "surface"; 0 = skip')
     ap.add_argument('--tile-bars', action='store_true',
                     help='headline = BASELINE.json configs[4] instead: ONE long clip (C=8, R=151, T=4) with its bars tiled over the '
                          '--gpus ranks (strong scaling)')
@@ -471,6 +520,8 @@ def main():
         if world == 1 and B == 1 and not batched and args.batched_clips > 1:
             del plan, ws                     # the one-clip workspaces are no longer needed
             out['batched'] = batched_leg(native, nat, dev, flat, args.batched_clips, args.batched_passes, 3)
+        if world == 1 and B == 1 and not batched and args.surface_steps > 0:
+            out['surface'] = surface_leg(dev, clip, args.surface_steps, 20)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(flat, table, clip, args.cpu_seconds)
         print(json.dumps(out))

@@ -196,18 +196,27 @@ class StyleTransferModel(nn.Module):
             raise _native.MstError(f'layer widths {widths} are outside the instantiated HIP kernels '
                                    '(melody_size must be 8 or 4; LSTM hidden sizes <= 256)')
         self._flat = self._gflat = None
-        self._offsets = None
+        self._offsets = self._ends = None
+        self.graph_repeated_shapes = True       # train_iteration(): replay a hipGraph when a clip shape comes back
 
     # ---- flat parameter / gradient buffers -------------------------------------------------
     def _sync_flat(self):
         """Point every Parameter's storage into ONE flat fp32 buffer laid out as the C ABI expects
         (model.parameters() order).  Re-done if the parameters moved (.to(), load_state_dict of new tensors)."""
+        # fast path (every forward of a training loop): the first and the last parameter still alias the flat buffer where
+        # they should.  Whatever re-homes parameters (.to(), load_state_dict(assign=True), ...) moves them all.
+        ends = getattr(self, '_ends', None)
+        if self._flat is not None and ends is not None:
+            base = self._flat.data_ptr()
+            if ends[0][0].data_ptr() == base + 4 * ends[0][1] and ends[1][0].data_ptr() == base + 4 * ends[1][1]:
+                return
         named = list(self.named_parameters())
         dev = named[0][1].device
         if dev.type != 'cuda':
             raise _native.MstError('the MI355X path needs the model on a GPU (model.to("cuda")); there is no CPU fallback')
         if self._flat is not None and self._flat.device == dev and all(
                 p.data_ptr() == self._flat.data_ptr() + 4 * off for (_, p), off in zip(named, self._offsets)):
+            self._ends = ((named[0][1], self._offsets[0]), (named[-1][1], self._offsets[-1]))
             return
         table = _native.get().param_table(_dims(**self._widths))
         if [n for n, _ in named] != [n for n, _, _ in table]:
@@ -220,9 +229,14 @@ class StyleTransferModel(nn.Module):
             p.data = flat[off:off + p.numel()].view(shape)
         self._flat, self._gflat = flat, torch.zeros_like(flat)
         self._offsets = [off for _, off, _ in table]
+        self._ends = ((named[0][1], self._offsets[0]), (named[-1][1], self._offsets[-1]))
 
     def _grad_target(self):
         """Where backward accumulates: the flat gradient buffer, aliased by every p.grad."""
+        (p0, o0), (p1, o1) = self._ends            # fast path: first and last p.grad alias the flat gradient buffer
+        gb = self._gflat.data_ptr()
+        if p0.grad is not None and p1.grad is not None and p0.grad.data_ptr() == gb + 4 * o0 and p1.grad.data_ptr() == gb + 4 * o1:
+            return self._gflat
         params = list(self.parameters())
         mine = [p.grad is not None and p.grad.data_ptr() == self._gflat.data_ptr() + 4 * off
                 for p, off in zip(params, self._offsets)]
@@ -233,6 +247,8 @@ class StyleTransferModel(nn.Module):
         return self._gflat
 
     def _publish_grads(self):
+        if self._ends[0][0].grad is not None and self._ends[1][0].grad is not None:
+            return
         for p, off in zip(self.parameters(), self._offsets):
             if p.grad is None:
                 p.grad = self._gflat[off:off + p.numel()].view(p.shape)
@@ -257,6 +273,46 @@ class StyleTransferModel(nn.Module):
         x_pitched, x_unpitched = _Apply.apply(self, self._anchor(), torch.is_grad_enabled(), style, melody, rhythm,
                                               instruments_features, bool(unpitched))
         return x_pitched, (x_unpitched if unpitched else None)
+
+    def train_iteration(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels, used_instruments, bpm_target):
+        """Opt-in fast form of one train-model.py loop body (train-model.py:113-126): forward, get_total_loss(normalize=True)
+        with the inputs as targets, and loss.backward() in ONE C-ABI call (mst_train_iteration) — no autograd graph, no
+        per-stage Python.  Gradients accumulate into the same flat buffer p.grad aliases, so optimizer.step() follows as
+        usual.  Returns the 15 loss leaves as one device tensor (key order style._native.LOSS_KEYS)."""
+        anchor = self._anchor()
+        dev = anchor.device
+        pitched = _f32c(pitched_channels, dev)
+        unpitched = None if unpitched_channels is None else _f32c(unpitched_channels, dev)
+        _, C, R, T = pitched.shape[:4]
+        plan = self._plan(C, R, T, unpitched is not None, dev)
+        plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instruments_features, dev),
+                        used=_f32c(used_instruments, dev), bpm_target=torch.as_tensor(float(bpm_target), dtype=torch.float32))
+        gflat = self._grad_target()
+        # A shape seen before replays a hipGraph of the whole loop body (the launches of mst_train_iteration captured once
+        # per plan over static input buffers); songs of a new shape run eagerly.  The graph is keyed by the buffers it baked in.
+        key = (self._flat.data_ptr(), gflat.data_ptr())
+        g = plan.graph if getattr(plan, 'graph_key', None) == key else None
+        if g is None and getattr(plan, 'uses', 0) >= 1 and dev.type == 'cuda' and getattr(self, 'graph_repeated_shapes', True):
+            # (the plan has run eagerly before, so its code objects are loaded: capturing executes nothing and needs no warm-up)
+            st = plan.static = dict(pitched=torch.empty_like(pitched), unpitched=None if unpitched is None else torch.empty_like(unpitched),
+                                    losses=torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plan.train_iteration(self._flat, gflat, st['pitched'], st['unpitched'], st['losses'])
+            plan.graph, plan.graph_key = g, key
+        plan.uses = getattr(plan, 'uses', 0) + 1
+        if g is not None:
+            st = plan.static
+            st['pitched'].copy_(pitched)
+            if unpitched is not None:
+                st['unpitched'].copy_(unpitched)
+            g.replay()
+            self._publish_grads()
+            return st['losses'].clone()
+        losses = torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev)
+        plan.train_iteration(self._flat, gflat, pitched, unpitched, losses)
+        self._publish_grads()
+        return losses
 
     def forward(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
         ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), torch.is_grad_enabled(), mode, bpm, pitched_channels,

@@ -108,8 +108,10 @@ class LossLog:
 
 
 def train(model, inputs, n_iterations=5000, iter_size=2, training_info_path='training.csv', save_path='snapshots/',
-          save_interval=100, flush_every=20, progress=True, optimizer=None):
-    """`inputs`: iterator of (filename, get_input(...)) tuples, e.g. iter_parallel(iter_inputs(...))."""
+          save_interval=100, flush_every=20, progress=True, optimizer=None, fused=True):
+    """`inputs`: iterator of (filename, get_input(...)) tuples, e.g. iter_parallel(iter_inputs(...)).
+    fused=True runs a loop body as ONE C-ABI call (StyleTransferModel.train_iteration: same arithmetic, same gradients, no
+    autograd graph); fused=False is the reference's own sequence model(...) -> get_total_loss -> backward."""
     optimizer = optimizer or FusedAdam(model, lr=.01, step_size=200, gamma=.9)
     optimizer.zero_grad()
     pbar = ProgressBar(n_iterations) if progress else None
@@ -123,11 +125,15 @@ def train(model, inputs, n_iterations=5000, iter_size=2, training_info_path='tra
         info = input[1][0]
         mode, bpm, pitched, features, unpitched = prepare_input(input, max_n_bars)
         used = get_used_instruments(features, unpitched)
-        (instruments_pred, mode_pred, bpm_pred), pitched_pred, unpitched_pred = model(mode, bpm, pitched, features, unpitched)
-        losses = get_total_loss(instruments_pred, used, bpm_pred, info['bpm'], mode_pred, mode, pitched_pred, pitched,
-                                unpitched_pred, unpitched, normalize=True)
-        losses['total'].backward()
-        log.add(iteration, losses.packed)
+        if fused:
+            packed = model.train_iteration(mode, bpm, pitched, features, unpitched, used, info['bpm'])
+        else:
+            (instruments_pred, mode_pred, bpm_pred), pitched_pred, unpitched_pred = model(mode, bpm, pitched, features, unpitched)
+            losses = get_total_loss(instruments_pred, used, bpm_pred, info['bpm'], mode_pred, mode, pitched_pred, pitched,
+                                    unpitched_pred, unpitched, normalize=True)
+            losses['total'].backward()
+            packed = losses.packed
+        log.add(iteration, packed)
         if (iteration + 1) % iter_size == 0:
             optimizer.step()                      # Adam + StepLR + zero_grad in one launch
         if iteration % save_interval == 0 and save_path:

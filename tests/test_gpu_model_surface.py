@@ -196,6 +196,29 @@ def test_two_pending_forwards_of_one_shape_keep_their_own_activations():
         style.sum().backward()
 
 
+def test_fused_train_iteration_eager_then_graph_replay():
+    """StyleTransferModel.train_iteration: the loop body as one C-ABI call.  First use of a clip shape runs eagerly, the second
+    captures a hipGraph, later ones replay it: same losses, gradients accumulate exactly like three backward() calls."""
+    z, model = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    clip = to_dev(synth_clip(0, C, R, T, True, density=float(z['density'])))
+    packed = [model.train_iteration(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'],
+                                    clip['used_instruments'], clip['bpm_int']).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert abs(float(packed[0][0]) - float(z['loss0/total'])) < 2e-5
+    assert torch.equal(packed[0].nan_to_num(-1.), packed[1].nan_to_num(-1.)) and torch.equal(packed[1].nan_to_num(-1.), packed[2].nan_to_num(-1.))
+    for n, p in model.named_parameters():
+        ref = 3.0 * z['g0/' + n]
+        if np.linalg.norm(ref) > 1e-12:
+            assert rel(p.grad.cpu().numpy(), ref) < 5e-4, n
+    # a different clip of the same shape through the replayed graph
+    model.zero_grad()
+    clip1 = to_dev(synth_clip(1, C, R, T, True, density=float(z['density'])))
+    l1 = model.train_iteration(clip1['mode'], clip1['bpm'], clip1['pitched'], clip1['instruments_features'], clip1['unpitched'],
+                               clip1['used_instruments'], clip1['bpm_int'])
+    assert abs(float(l1[0]) - float(z['loss1/total'])) < 2e-5
+
+
 def test_style_swap_inference_matches_reference_fixture():
     """style/style_transfer.py:41-54,101-131 through the product surface: style of song B (pitched only,
     unpitched_channels=None) on melody + rhythm of song A, then hard_output — against outputs of the reference."""

@@ -88,7 +88,8 @@ def test_drop_silent_and_loss_log(tmp_path):
 
 
 @pytest.mark.gpu
-def test_train_loop_matches_oracle_trajectory(tmp_path):
+@pytest.mark.parametrize('fused', [True, False])
+def test_train_loop_matches_oracle_trajectory(tmp_path, fused):
     from oracle import style_oracle as so
     from style import style_transfer as st
     from style.data import prepare_input, get_used_instruments
@@ -98,8 +99,9 @@ def test_train_loop_matches_oracle_trajectory(tmp_path):
     named = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in model.named_parameters()}
     start = torch.cat([p.detach().reshape(-1) for p in named.values()])
     csv_path, snap = str(tmp_path / 'training.csv'), str(tmp_path / 'snapshots')
+    # fused: a loop body as one C-ABI call (the default); not fused: the reference's sequence through autograd
     train(model, iter(songs), n_iterations=4, iter_size=2, training_info_path=csv_path, save_path=snap, save_interval=2,
-          flush_every=3, progress=False)
+          flush_every=3, progress=False, fused=fused)
     rows = list(csv.DictReader(open(csv_path)))
     assert [int(r['iteration']) for r in rows] == [0, 1, 2, 3]
     assert sorted(os.listdir(snap)) == ['0.pkl', '2.pkl']

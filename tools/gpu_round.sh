@@ -14,6 +14,8 @@ try:
     d = json.loads(open('gpurun_out/${TAG}_bench.json').read().strip().splitlines()[-1])
     b = d.get('batched') or {}
     print('one clip: %.0f it/s, %.3f ms; roofline %s frac %.4f' % (d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac']))
+    s_ = d.get("surface") or {}
+    if s_: print("surface: %.0f it/s, %.3f ms" % (s_["value"], s_["ms_per_step"]))
     if b: print('batched: %.0f clip-it/s, %.2f ms/pass; %s %.1f TF frac %.3f' % (b['value'], b['ms_per_pass'], b['roofline']['kernel'], b['roofline']['achieved'], b['roofline']['frac']))
     print('cpu', d.get('cpu_baseline', {}).get('value'))
 except Exception as e:
