@@ -87,10 +87,31 @@ class _Container(nn.Module):
                 mod = Distributed(mod, depth=_DEPTH[(self._prefix, child)])
             setattr(self, child, mod)
 
+    def _owner(self):
+        ref = self.__dict__.get('_parent')
+        model = ref() if ref is not None else None
+        if model is None:
+            raise NotImplementedError(
+                f'{type(self).__name__} is a parameter container on the MI355X path: its arithmetic is fused into the HIP kernels '
+                'behind StyleTransferModel.extract_style / predict_song_info / apply_style / forward, and it can only be called '
+                'on its own once it is part of a StyleTransferModel (the kernels need the whole flat parameter buffer).')
+        return model
+
     def forward(self, *args, **kwargs):
+        self._owner()
         raise NotImplementedError(
-            f'{type(self).__name__} is a parameter container on the MI355X path: its arithmetic is fused into the HIP '
-            'kernels behind StyleTransferModel.extract_style / predict_song_info / apply_style / forward.')
+            f'{type(self).__name__}.forward takes intermediate tensors (beats / bars) that the fused plan does not accept as inputs; '
+            'call StyleTransferModel.extract_style instead.  Stand-alone forwards exist for the channel encoders, SongInfoModel and '
+            'the two style appliers (INTEGRATION.md section 2).')
+
+    def __getstate__(self):          # the back-reference to the owning model is rebuilt by StyleTransferModel, never pickled
+        d = dict(self.__dict__)
+        d.pop('_parent', None)
+        return d
+
+
+def _named_slots(model, plan, names, shapes):
+    return tuple(plan.view(n, s).clone() for n, s in zip(names, shapes))
 
 
 class PitchedChannelsEncoder(_Container):
@@ -101,6 +122,19 @@ class PitchedChannelsEncoder(_Container):
         assert bar_size % 2 == 0
         self._build(beat=beat_size, bar=bar_size, instr=instrument_size)
 
+    def forward(self, x, instruments_features):
+        """style/model.py:77-99 on its own (forward only, no autograd): (beats (1,C,R,T,beat), bars (1,R,bar)).  Runs the
+        extract stage of the owning model's plan and returns its named slots."""
+        model = self._owner()
+        with torch.no_grad():
+            dev = model._anchor().device
+            x = _f32c(x, dev)
+            _, C, R, T = x.shape[:4]
+            plan = model._plan(C, R, T, False, dev)
+            plan.set_inputs(mode=torch.tensor([1., 0.]), bpm=torch.tensor([120.]), instr=_f32c(instruments_features, dev))
+            plan.forward(_native.STAGE_EXTRACT, model._flat, x, None)
+            return _named_slots(model, plan, ('pitched_beats', 'pitched_bars'), ((1, C, R, T, -1), (1, R, -1)))
+
 
 class UnpitchedChannelsEncoder(_Container):
     _prefix = 'unpitched_channels_encoder'
@@ -109,6 +143,20 @@ class UnpitchedChannelsEncoder(_Container):
         super().__init__()
         assert bar_size % 2 == 0
         self._build(beat=beat_size, bar=bar_size)
+
+    def forward(self, x):
+        """style/model.py:128-141 on its own (forward only): (beats (1,1,R,T,beat), bars (1,R,bar)).  The plan needs a pitched
+        tensor beside it; an all-zero single channel is supplied (the unpitched encoder does not read it)."""
+        model = self._owner()
+        with torch.no_grad():
+            dev = model._anchor().device
+            x = _f32c(x, dev)
+            _, _, R, T = x.shape[:4]
+            plan = model._plan(1, R, T, True, dev)
+            pitched = torch.zeros(1, 1, R, T, n_beat_fractions, n_pitched_notes, n_pitched_features, device=dev)
+            plan.set_inputs(mode=torch.tensor([1., 0.]), bpm=torch.tensor([120.]), instr=torch.zeros(1, model._widths.get('instr', 51)))
+            plan.forward(_native.STAGE_EXTRACT, model._flat, pitched, x)
+            return _named_slots(model, plan, ('unpitched_beats', 'unpitched_bars'), ((1, 1, R, T, -1), (1, R, -1)))
 
 
 class StyleEncoder(_Container):
@@ -150,6 +198,10 @@ class SongInfoModel(_Container):
         super().__init__()
         self._build(nrf=n_rhythm_features, style=style_size, rhythm=rhythm_size, n_instruments=n_instruments)
 
+    def forward(self, style, rhythm):
+        """style/model.py:557-562 = StyleTransferModel.predict_song_info (differentiable)."""
+        return self._owner().predict_song_info(style, rhythm)
+
 
 class PitchedStyleApplier(_Container):
     _prefix = 'pitched_style_applier'
@@ -158,6 +210,10 @@ class PitchedStyleApplier(_Container):
         super().__init__()
         self._build(style=style_size, melody=melody_size, rhythm=rhythm_size, instr=instrument_size)
 
+    def forward(self, style, melody, rhythm, instruments):
+        """style/model.py:624-675 = the pitched half of StyleTransferModel.apply_style (differentiable)."""
+        return self._owner().apply_style(style, melody, rhythm, instruments, unpitched=False)[0]
+
 
 class UnpitchedStyleApplier(_Container):
     _prefix = 'unpitched_style_applier'
@@ -165,6 +221,17 @@ class UnpitchedStyleApplier(_Container):
     def __init__(self, style_size, rhythm_size):
         super().__init__()
         self._build(style=style_size, rhythm=rhythm_size)
+
+    def forward(self, style, rhythm):
+        """style/model.py:703-724 (forward only): the unpitched half of apply_style; a zero melody and one blank instrument row
+        stand in for the pitched applier's inputs, which this module does not read."""
+        model = self._owner()
+        with torch.no_grad():
+            R, T = rhythm.shape[1:3]
+            w = dict(_DEFAULT_WIDTHS); w.update(model._widths)
+            melody = torch.zeros(1, R, T, n_beat_fractions, n_pitched_notes, w['melody'], device=rhythm.device)
+            instr = torch.zeros(1, 1, w['instr'], device=rhythm.device)
+            return model.apply_style(style, melody, rhythm, instr, unpitched=True)[1]
 
 
 def _f32c(t, dev):
@@ -191,6 +258,7 @@ class StyleTransferModel(nn.Module):
                 if widths.setdefault(k, v) != v:
                     raise ValueError(f'sub-modules disagree on {k}_size: {widths[k]} vs {v}')
         self._widths = widths
+        self._link_children()
         # fail here, not at the first forward: the note-level HIP kernels exist for melody_size 8 and 4 only
         if _native.get().lib.mst_widths_supported(_dims(**widths)) != 0:
             raise _native.MstError(f'layer widths {widths} are outside the instantiated HIP kernels '
@@ -198,6 +266,15 @@ class StyleTransferModel(nn.Module):
         self._flat = self._gflat = None
         self._offsets = self._ends = None
         self.graph_repeated_shapes = True       # train_iteration(): replay a hipGraph when a clip shape comes back
+
+    def _link_children(self):
+        import weakref
+        for _, child in self.named_children():       # lets a sub-module be called on its own (see _Container.forward)
+            child.__dict__['_parent'] = weakref.ref(self)
+
+    def __setstate__(self, state):                   # whole-module snapshots (train-model.py:156-160): re-link after unpickling
+        super().__setstate__(state)
+        self._link_children()
 
     # ---- flat parameter / gradient buffers -------------------------------------------------
     def _sync_flat(self):

@@ -219,6 +219,35 @@ def test_fused_train_iteration_eager_then_graph_replay():
     assert abs(float(l1[0]) - float(z['loss1/total'])) < 2e-5
 
 
+def test_sub_modules_called_on_their_own():
+    """The reference's sub-modules are callable (style/model.py:77-99,128-141,557-562,624-675,703-724); here the channel
+    encoders, SongInfoModel and the two appliers run through the owning model's plan, against the reference's fixture."""
+    import io
+    z, model = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    clip = to_dev(synth_clip(0, C, R, T, True, density=float(z['density'])))
+    beats, bars = model.pitched_channels_encoder(clip['pitched'], clip['instruments_features'])
+    assert rel(beats.cpu(), z['mid/pitched_channels_encoder/0']) < 1e-4 and rel(bars.cpu(), z['mid/pitched_channels_encoder/1']) < 1e-4
+    ub, ubars = model.unpitched_channels_encoder(clip['unpitched'])
+    assert rel(ub.cpu(), z['mid/unpitched_channels_encoder/0']) < 1e-4 and rel(ubars.cpu(), z['mid/unpitched_channels_encoder/1']) < 1e-4
+    with torch.no_grad():
+        style, melody, rhythm = model.extract_style(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+        ip, mp, bp = model.song_info_model(style, rhythm)
+        xp = model.pitched_style_applier(style, melody, rhythm, clip['instruments_features'])
+        xu = model.unpitched_style_applier(style, rhythm)
+    assert rel(ip.cpu(), z['out/instruments']) < 1e-4 and rel(xp.cpu(), z['out/pitched']) < 1e-4 and rel(xu.cpu(), z['out/unpitched']) < 1e-4
+    import style.model as m
+    with pytest.raises(NotImplementedError):
+        model.melody_encoder(beats, bars, clip['pitched'], clip['instruments_features'])
+    with pytest.raises(NotImplementedError):                     # not part of a model: only a parameter container
+        m.SongInfoModel(3, 12, 6, 41)(style, rhythm)
+    buf = io.BytesIO()
+    torch.save(model, buf)                                        # whole-module snapshot keeps the sub-modules callable
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert rel(again.song_info_model(style, rhythm)[0].detach().cpu(), z['out/instruments']) < 1e-4
+
+
 def test_style_swap_inference_matches_reference_fixture():
     """style/style_transfer.py:41-54,101-131 through the product surface: style of song B (pitched only,
     unpitched_channels=None) on melody + rhythm of song A, then hard_output — against outputs of the reference."""
