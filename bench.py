@@ -317,6 +317,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel time table to stderr')
+    ap.add_argument('--no-roofline', action='store_true',
+                    help='skip the per-step timing leg (PMC runs: its 2 x 21 extra launches of every step would count as traffic)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only to rehearse N>1 on one GPU')
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     ap.add_argument('--clips-per-gpu', type=int, default=1,
@@ -487,7 +489,7 @@ def main():
 
         # ---- roofline leg: every launch step timed with HIP events on this stream (same workload)
         roof, table_rows = None, []
-        if rank == 0:
+        if rank == 0 and not args.no_roofline:
             roof, table_rows = roofline_leg(plan, nat, params, gparams, xp, xu, K, dt / args.steps, args.breakdown)
 
     ips = world * args.steps / dt

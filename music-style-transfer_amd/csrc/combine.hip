@@ -10,10 +10,11 @@
 #include "mst_common.h"
 
 // sums `nv` per-lane values across the 256-lane workgroup; result for value v lands in red[v]
+template <int MC = COMBINE_MAXC>
 __device__ __forceinline__ void block_sum_multi(float* vals, int nv, float (*part)[COMBINE_MAXC + 1], float* red) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int v = 0; v <= COMBINE_MAXC; ++v) {       // static indices keep vals[] in registers; nv is workgroup-uniform
+    for (int v = 0; v <= MC; ++v) {                 // static indices keep vals[] in registers; nv is workgroup-uniform
         if (v < nv) {
             float x = vals[v];
 #pragma unroll
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDes
 
 // Small sites (<= COMBINE_SMALL elements per slice: the per-bar tensors, the style vector) need no cross-workgroup
 // re-sum: one workgroup per site does reduction and elementwise pass in ONE launch instead of two.
+// MC: compile-time bound on the channel count (4: every site of the model up to 4 channels — unrolled loops and shuffle
+// reductions over 32 mostly absent channels were most of these kernels' ~10 us; 32: the general case)
+template <int MC>
 __global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDesc* __restrict__ descs, Bases b) {
     const CombineDesc d = descs[blockIdx.x];
     __shared__ float nrm[COMBINE_MAXC + 1];
@@ -166,17 +170,17 @@ __global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDes
     float* ws = b.p[SP_WS];
     float* tmp = b.p[SP_TMP];
     const int n = d.rows * d.cols;
-    float acc[COMBINE_MAXC + 1];
+    float acc[MC + 1];
 #pragma unroll
-    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int c = 0; c <= MC; ++c) acc[c] = 0.f;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int64_t eo = elem_off(d, e);
 #pragma unroll
-        for (int c = 0; c < COMBINE_MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             if (c < d.Cn) { const float v = ws[d.x_off + (int64_t)c * d.cs + eo]; acc[c] = fmaf(v, v, acc[c]); }
         }
     }
-    block_sum_multi(acc, d.Cn, part, red);
+    block_sum_multi<MC>(acc, d.Cn, part, red);
     if ((int)threadIdx.x < d.Cn) nrm[threadIdx.x] = sqrtf(1.f + red[threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDes
     }
 }
 
+template <int MC>
 __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDesc* __restrict__ descs, Bases b) {
     const CombineDesc d = descs[blockIdx.x];
     __shared__ float coef[COMBINE_MAXC + 1];
@@ -204,25 +209,25 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
     float* gr = b.p[SP_GRAD];
     const float* tmp = b.p[SP_TMP];
     const int n = d.rows * d.cols;
-    float acc[COMBINE_MAXC + 1];
+    float acc[MC + 1];
 #pragma unroll
-    for (int c = 0; c <= COMBINE_MAXC; ++c) acc[c] = 0.f;
+    for (int c = 0; c <= MC; ++c) acc[c] = 0.f;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int64_t eo = elem_off(d, e);
         const float g = gr[d.gout_off + e];
 #pragma unroll
-        for (int c = 0; c < COMBINE_MAXC; ++c) {
+        for (int c = 0; c < MC; ++c) {
             if (c < d.Cn) acc[c] = fmaf(g, ws[d.x_off + (int64_t)c * d.cs + eo], acc[c]);
         }
-        acc[COMBINE_MAXC] = fmaf(g, ws[d.out_off + e], acc[COMBINE_MAXC]);
+        acc[MC] = fmaf(g, ws[d.out_off + e], acc[MC]);
     }
-    float vals[COMBINE_MAXC + 1];
+    float vals[MC + 1];
 #pragma unroll
-    for (int c = 0; c < COMBINE_MAXC; ++c) vals[c] = acc[c];
-    vals[COMBINE_MAXC] = 0.f;
+    for (int c = 0; c < MC; ++c) vals[c] = acc[c];
+    vals[MC] = 0.f;
 #pragma unroll
-    for (int c = 0; c <= COMBINE_MAXC; ++c) if (c == d.Cn) vals[c] = acc[COMBINE_MAXC];
-    block_sum_multi(vals, d.Cn + 1, part, coef);
+    for (int c = 0; c <= MC; ++c) if (c == d.Cn) vals[c] = acc[MC];
+    block_sum_multi<MC>(vals, d.Cn + 1, part, coef);
     if ((int)threadIdx.x <= d.Cn) nc_s[threadIdx.x] = tmp[d.stats_off + threadIdx.x];       // n_c ..., S
     __syncthreads();
     const float S = nc_s[d.Cn];
@@ -240,11 +245,12 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
     }
 }
 
-// all_small: every site of the (merged) launch has <= COMBINE_SMALL elements per slice
+// all_small: every site of the (merged) launch has <= COMBINE_SMALL elements per slice (2: and at most 4 channels)
 int launch_combine_fwd(const CombineDesc* dev, int count, int max_nblk, int all_small, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
     if (all_small) {
-        hipLaunchKernelGGL(combine_small_fwd_kernel, dim3(count), dim3(256), 0, s, dev, b);
+        if (all_small == 2) hipLaunchKernelGGL(combine_small_fwd_kernel<4>, dim3(count), dim3(256), 0, s, dev, b);
+        else hipLaunchKernelGGL(combine_small_fwd_kernel<COMBINE_MAXC>, dim3(count), dim3(256), 0, s, dev, b);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(combine_sumsq_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);
@@ -255,7 +261,8 @@ int launch_combine_fwd(const CombineDesc* dev, int count, int max_nblk, int all_
 int launch_combine_bwd(const CombineDesc* dev, int count, int max_nblk, int all_small, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
     if (all_small) {
-        hipLaunchKernelGGL(combine_small_bwd_kernel, dim3(count), dim3(256), 0, s, dev, b);
+        if (all_small == 2) hipLaunchKernelGGL(combine_small_bwd_kernel<4>, dim3(count), dim3(256), 0, s, dev, b);
+        else hipLaunchKernelGGL(combine_small_bwd_kernel<COMBINE_MAXC>, dim3(count), dim3(256), 0, s, dev, b);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(combine_bwd_reduce_kernel, dim3(max_nblk, count), dim3(256), 0, s, dev, b);

@@ -790,20 +790,24 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
     const int rows = e.reps * e.splits;
     const int r0 = (int)((int64_t)rows * g / 4), r1 = (int)((int64_t)rows * (g + 1) / 4);
     const int i = blk.start + lane;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;              // 4 independent chains keep 4+ loads in flight
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent chains keep 8 loads in flight
     if (i < e.count) {
         const float* src = b.p[SP_TMP] + e.src + i;
         int rep = r0 / e.splits, sp = r0 - rep * e.splits;
         int r = r0;
-        for (; r + 4 <= r1; r += 4) {
-            int64_t o[4];
+        for (; r + 8 <= r1; r += 8) {
+            int64_t o[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { o[q] = (int64_t)rep * e.rep_stride + (int64_t)sp * e.stride; if (++sp == e.splits) { sp = 0; ++rep; } }
-            const float v0 = src[o[0]], v1 = src[o[1]], v2 = src[o[2]], v3 = src[o[3]];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            for (int q = 0; q < 8; ++q) { o[q] = (int64_t)rep * e.rep_stride + (int64_t)sp * e.stride; if (++sp == e.splits) { sp = 0; ++rep; } }
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[o[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += v[q];
         }
-        for (; r < r1; ++r) { a0 += src[(int64_t)rep * e.rep_stride + (int64_t)sp * e.stride]; if (++sp == e.splits) { sp = 0; ++rep; } }
+        for (; r < r1; ++r) { a[0] += src[(int64_t)rep * e.rep_stride + (int64_t)sp * e.stride]; if (++sp == e.splits) { sp = 0; ++rep; } }
     }
+    const float a0 = a[0] + a[4], a1 = a[1] + a[5], a2 = a[2] + a[6], a3 = a[3] + a[7];
     part[g][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (g == 0 && i < e.count) {

@@ -74,22 +74,35 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
         } else if (tid < G) {
             // thread per gate row over the transposed copy: lane-contiguous (coalesced) reads, 4 chains
             // summed as four quarters of k, each four interleaved chains, then (q0 + q1) + (q2 + q3): the association of the
-            // multi-workgroup flavour below, so a clip's activations are bit-identical in one-clip and batched plans
+            // multi-workgroup flavour below, so a clip's activations are bit-identical in one-clip and batched plans.  The
+            // four quarters advance together: sixteen independent loads per trip
             const float* wt = tmp + d.whht_off + tid;
-            const int KQ = (H % 16 == 0) ? H / 4 : H;
             float qs[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int qq = 0; qq * KQ < H; ++qq) {
+            if (H % 16 == 0) {
+                const int KQ = H / 4;
+                float a[4][4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { a[qq][0] = 0.f; a[qq][1] = 0.f; a[qq][2] = 0.f; a[qq][3] = 0.f; }
+                for (int k = 0; k < KQ; k += 4) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[qq][i] = fmaf(wt[(int64_t)(qq * KQ + k + i) * G], h_s[qq * KQ + k + i], a[qq][i]);
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) qs[qq] = (a[qq][0] + a[qq][1]) + (a[qq][2] + a[qq][3]);
+            } else {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                int k = qq * KQ;
-                const int ke = k + KQ;
-                for (; k + 4 <= ke; k += 4) {
+                int k = 0;
+                for (; k + 4 <= H; k += 4) {
                     a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
                     a1 = fmaf(wt[(int64_t)(k + 1) * G], h_s[k + 1], a1);
                     a2 = fmaf(wt[(int64_t)(k + 2) * G], h_s[k + 2], a2);
                     a3 = fmaf(wt[(int64_t)(k + 3) * G], h_s[k + 3], a3);
                 }
-                for (; k < ke; ++k) a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
-                qs[qq] = (a0 + a1) + (a2 + a3);
+                for (; k < H; ++k) a0 = fmaf(wt[(int64_t)k * G], h_s[k], a0);
+                qs[0] = (a0 + a1) + (a2 + a3);
             }
             z_s[tid] = (qs[0] + qs[1]) + (qs[2] + qs[3]);
         }
@@ -196,20 +209,31 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
             } else {
                 const float* wc = whh + (int64_t)part * H * H + kk;      // coalesced along kk
                 const float* dzp = dz_s + part * H;
-                const int CH = chunked ? H / 4 : H;                      // rows per chunk (48 at H = 192)
-                for (int ci = 0; ci * CH < H; ++ci) {
+                if (chunked) {                                            // four 48-row chunks advance together: 16 loads per trip
+                    const int CH = H / 4;
+                    float a[4][4];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) { a[ci][0] = 0.f; a[ci][1] = 0.f; a[ci][2] = 0.f; a[ci][3] = 0.f; }
+                    for (int jj = 0; jj < CH; jj += 4) {
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) a[ci][i] = fmaf(wc[(int64_t)(ci * CH + jj + i) * H], dzp[ci * CH + jj + i], a[ci][i]);
+                        }
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) cacc[ci] = (a[ci][0] + a[ci][1]) + (a[ci][2] + a[ci][3]);
+                } else {
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                    int jj = ci * CH;
-                    const int je = jj + CH;
-                    for (; jj + 4 <= je; jj += 4) {
+                    int jj = 0;
+                    for (; jj + 4 <= H; jj += 4) {
                         a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
                         a1 = fmaf(wc[(int64_t)(jj + 1) * H], dzp[jj + 1], a1);
                         a2 = fmaf(wc[(int64_t)(jj + 2) * H], dzp[jj + 2], a2);
                         a3 = fmaf(wc[(int64_t)(jj + 3) * H], dzp[jj + 3], a3);
                     }
-                    for (; jj < je; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
+                    for (; jj < H; ++jj) a0 = fmaf(wc[(int64_t)jj * H], dzp[jj], a0);
                     acc = (a0 + a1) + (a2 + a3);
-                    if (chunked) cacc[ci] = acc;
                 }
             }
         }

@@ -165,6 +165,7 @@ struct NotesDesc {
     // pre-activations decompose: z[c, qf] = rt[qf] + it[c] (it carries the style part and the bias).  [SP_WS]
     int64_t rt_oct_off, rt_deg_off;      // (Q*F, 240), (Q*F, 210)
     int64_t it_oct_off, it_deg_off;      // (C, 240), (C, 210)
+    // (the backward kernel sums dL/dz over the channels itself and writes the rt gradients at the same offsets in SP_GRAD)
     int64_t x_off; int32_t x_space;  // ME: pitched input
     int64_t ml_off;              // PSA: (Q*F*56, ML)
     int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
     __shared__ __attribute__((aligned(16))) float dz_s[4][2][NPN][8];      // [wave][row A|B][note][5 used of 8]
     __shared__ __attribute__((aligned(16))) float dzs_s[4][2][NPN][8];     // channel sums, same layout
     __shared__ float lo_s[4][NOCT][64];                                     // the row pair's octave rows, [octave][lane]
+    __shared__ float rto_s[4][NOCT + NDEG][64];                             // dL/dz summed over the channels of this qf (= g_rt)
     __shared__ float red_s[4][NPF][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, jl = lane & 31;
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
     float dzsum[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) dzsum[q] = 0.f;
+#pragma unroll
+    for (int o = 0; o < NOCT + NDEG; ++o) rto_s[wv][o][lane] = 0.f;
     while (have) {                                         // wave-uniform
         int nqf = qf, nc0 = c0 + 2;
         if (nc0 >= d.C) { nc0 = 0; nqf = qf + stride; }
@@ -555,14 +558,30 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
                 dlo += g; dld[dg] += g;
             }
             // gradient of the PRE-activation (leaky' from the activation's sign); sole writer of this row
-            if (jvalid && rvalid) glop[o * PSA_HW] = dlo * dlrelu(lo);
+            const float dzo = rvalid ? dlo * dlrelu(lo) : 0.f;
+            if (jvalid && rvalid) glop[o * PSA_HW] = dzo;
+            rto_s[wv][o][lane] += dzo;                     // lane-private slot: summed over the channels of this qf
         }
-        if (jvalid && rvalid) {
 #pragma unroll
-            for (int q = 0; q < NDEG; ++q) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dld[q] * dlrelu(cur.ld[q]);
+        for (int q = 0; q < NDEG; ++q) {
+            const float dzd = rvalid ? dld[q] * dlrelu(cur.ld[q]) : 0.f;
+            if (jvalid && rvalid) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dzd;
+            rto_s[wv][NOCT + q][lane] += dzd;
         }
         if (nc0 == 0) {
-            // ---- last pair of this qf: the melody-linear columns from the channel sums
+            // ---- last pair of this qf.  g_rt[qf] = sum over the channels of dL/dz (the two halves of the wave hold the even /
+            // odd channels): sole writer of this row of the rt gradients
+            MST_WAVE_SYNC();
+            if (half == 0 && jvalid) {
+#pragma unroll
+                for (int o = 0; o < NOCT; ++o) gr[d.rt_oct_off + (int64_t)qf * NLO + o * PSA_HW + j] = rto_s[wv][o][lane] + rto_s[wv][o][lane + 32];
+#pragma unroll
+                for (int q = 0; q < NDEG; ++q) gr[d.rt_deg_off + (int64_t)qf * NLD + q * PSA_HW + j] = rto_s[wv][NOCT + q][lane] + rto_s[wv][NOCT + q][lane + 32];
+            }
+            MST_WAVE_SYNC();
+#pragma unroll
+            for (int o = 0; o < NOCT + NDEG; ++o) rto_s[wv][o][lane] = 0.f;
+            // ---- the melody-linear columns from the channel sums
             MST_WAVE_SYNC();
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {

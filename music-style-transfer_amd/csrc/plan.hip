@@ -596,11 +596,12 @@ struct mst_plan {
     }
 
     // backward of "z[c, q] = rt[q] + it[c]" (rows c-major, `width` columns): g_rt[q] += sum_c g_z[c, q], g_it[c] += sum_q g_z[c, q]
-    void bcast_add_bwd(int stage, const T& gz, int Cn, int Qn, const T& rt, const T& it) {
+    // (with_rt = false: only g_it — the backward note kernel sums over the channels itself and writes g_rt)
+    void bcast_add_bwd(int stage, const T& gz, int Cn, int Qn, const T& rt, const T& it, bool with_rt) {
         Op op; op.stage = stage;
         const int first = (int)segreds.size();
         int maxidx = 1, stage2 = 0;
-        for (int which = 0; which < 2; ++which) {
+        for (int which = with_rt ? 0 : 1; which < 2; ++which) {
             SegRedDesc r{}; r.src_off = gz.off; r.src_ld = gz.ld; r.start = 0; r.width = gz.cols;
             const T& dst = which ? it : rt;
             r.dst_off = dst.off; r.dst_ld = dst.ld;
@@ -616,7 +617,7 @@ struct mst_plan {
             if (r.nidx * r.nchunk > maxidx) maxidx = r.nidx * r.nchunk;
             segreds.push_back(r);
         }
-        op.bwd.push_back(Step{K_SEGRED, first, 2, maxidx, stage2});
+        op.bwd.push_back(Step{K_SEGRED, first, (int)segreds.size() - first, maxidx, stage2});
         ops.push_back(op);
     }
 
@@ -895,7 +896,7 @@ void mst_plan::build() {
         linear_part(AP, psa_il, true, lin + ".weight", z.PSA_SL + z.PSA_RL, KA, "", &sb, Nw, it_x[which], 0);
         linear_part(AP, psa_rl, true, lin + ".weight", z.PSA_SL, KA, "", nullptr, Nw, rt_x[which], 0);
         gz_x[which] = newT(P_ * NF, Nw);                   // only its gradient slot is used
-        bcast_add_bwd(AP, gz_x[which], C, QF_, rt_x[which], it_x[which]);
+        bcast_add_bwd(AP, gz_x[which], C, QF_, rt_x[which], it_x[which], false);
     }
     T ml = rowlin(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
@@ -1151,6 +1152,8 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
                 acc_add(v, SP_GRAD, n.g_out_off, pos * outw, false);
                 acc_add(v, SP_GRAD, n.g_oct_off, rows * ow, true);
                 acc_add(v, SP_GRAD, n.g_deg_off, rows * dw, true);
+                acc_add(v, SP_GRAD, n.rt_oct_off, (int64_t)n.Q * NF * ow, true);       // channel sums of dL/dz = gradient of rt
+                acc_add(v, SP_GRAD, n.rt_deg_off, (int64_t)n.Q * NF * dw, true);
                 if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
                 acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
             }
@@ -1492,8 +1495,8 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, p->s_lstms[s.first].multi, b, st);
     case K_LSTM_F: return launch_lstm_fwd(p->d_lstms + s.first, s.count, s.a, s.b, p->s_lstms[s.first].multi, b, st);
     case K_LSTM_B: return launch_lstm_bwd(p->d_lstms + s.first, s.count, s.a, s.b, p->s_lstms[s.first].multi, b, st);
-    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
-    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0, b, st);
+    case K_COMB_F: return launch_combine_fwd(p->d_combines + s.first, s.count, s.a, s.b == 0 ? (p->d.C <= 4 ? 2 : 1) : 0, b, st);
+    case K_COMB_B: return launch_combine_bwd(p->d_combines + s.first, s.count, s.a, s.b == 0 ? (p->d.C <= 4 ? 2 : 1) : 0, b, st);
     case K_COMB_F1: return launch_combine_phase(p->d_combines + s.first, s.a, 0, b, st);
     case K_COMB_F2: return launch_combine_phase(p->d_combines + s.first, s.a, 1, b, st);
     case K_COMB_B1: return launch_combine_phase(p->d_combines + s.first, s.a, 2, b, st);

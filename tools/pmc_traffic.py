@@ -26,5 +26,13 @@ for k in ('gemm_kernel', 'gemm_mfma_kernel'):
     if k in fetch:
         fb, wb = fetch[k]['avg_kb_per_launch'] * 1024, write.get(k, dict(avg_kb_per_launch=0))['avg_kb_per_launch'] * 1024
         out[k] = dict(fetch_bytes_per_launch=fb, write_bytes_per_launch=wb, hbm_bytes_per_launch=fb + wb)
+# whole-pass traffic: every kernel's bytes summed, per training iteration (sys.argv[5] = iterations the command ran, warm-up included)
+if len(sys.argv) > 5:
+    # sys.argv[5] = clips per pass; passes = launches of loss_tail_kernel (one per pass, nothing else launches it)
+    iters = float(sys.argv[5]) * fetch['loss_tail_kernel']['launches']
+    tot_f = sum(v['launches'] * v['avg_kb_per_launch'] for v in fetch.values()) * 1024 / iters
+    tot_w = sum(v['launches'] * v['avg_kb_per_launch'] for v in write.values()) * 1024 / iters
+    out['per_iteration'] = dict(iterations=iters, fetch_bytes=tot_f, write_bytes=tot_w, hbm_bytes=tot_f + tot_w,
+                                note='all kernels of the run (model, loss, optimizer, copies) / iterations; raw counters')
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print({k: out[k] for k in out if k.startswith('gemm')})
