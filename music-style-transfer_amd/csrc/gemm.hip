@@ -401,6 +401,9 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     const int a_act = AK == OPK_ACTGRAD ? d.A.act : ACT_NONE;
     const int a_tr = d.A.transposed;
     const int b_ones = d.B.ones_at;
+    // clips folded into the reduction (weight gradients of a batched plan): k = (clip, row)
+    const int fr = d.fold_rows;
+    const int64_t acs = d.acs, acs2 = d.acs2, bcs = d.bcs;
     // group geometry.  KF = 1 (k is unit stride): row = (tid >> 3) + 32 g, k = 4 (tid & 7) + j.
     //                  KF = 0 (row is unit stride): k = (tid >> 4) + 16 g, row = 4 (tid & 15) + j.
     const int arow0 = AKF ? (tid >> 3) : 4 * (tid & 15), akl0 = AKF ? 4 * (tid & 7) : (tid >> 4);
@@ -414,10 +417,10 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
         for (int g = 0; g < 2; ++g) {
             const int mr = q.tm * MF_BM + arow0 + (AKF ? 32 * g : 0);
             q.avec[g] = AKF ? mr < M : mr + 3 < M;
-            q.aoff[g] = min(mr, M - 1) * sAm + (AKF ? akl0 : (akl0 + 16 * g) * sAk);
+            q.aoff[g] = min(mr, M - 1) * sAm + (AKF ? akl0 : 0);       // KF = 0: the k part is added per k-tile (folded clips)
             const int nr = q.tn * MF_BN + brow0 + (BKF ? 32 * g : 0);
             q.bvec[g] = BKF ? nr < N : (nr + 3 < N) & !((b_ones >= nr) & (b_ones <= nr + 3));
-            q.boff[g] = min(nr, N - 1) * sBn + (BKF ? bkl0 : (bkl0 + 16 * g) * sBk);
+            q.boff[g] = min(nr, N - 1) * sBn + (BKF ? bkl0 : 0);
         }
     };
     mf_f32x16 acc;
@@ -449,12 +452,14 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             } else {
                 const int kk = kt + akl0 + 16 * g;
                 const bool kok = kk < k1;
-                const int o = q.aoff[g] + kt * sAk;
+                const int clip = (fr && kok) ? kk / fr : 0, kr = fr ? kk - clip * fr : kk;
+                const gcptr pa = baseA + clip * acs, py = baseY + clip * acs2;
+                const int o = q.aoff[g] + kr * sAk;
                 if (q.avec[g] & kok) {
-                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (unsigned)o);
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(pa + (unsigned)o);
                     va[4 * g] = t[0]; va[4 * g + 1] = t[1]; va[4 * g + 2] = t[2]; va[4 * g + 3] = t[3];
                     if constexpr (AK == OPK_ACTGRAD) {
-                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseY + (unsigned)o);
+                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(py + (unsigned)o);
                         vy[4 * g] = u[0]; vy[4 * g + 1] = u[1]; vy[4 * g + 2] = u[2]; vy[4 * g + 3] = u[3];
                     }
                 } else {
@@ -462,9 +467,9 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = kok & (mr + j < M);
-                        const int oj = ok ? (mr + j) * sAm + kk * sAk : 0;
-                        va[4 * g + j] = ok ? baseA[(unsigned)oj] : 0.f;
-                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? baseY[(unsigned)oj] : 0.f;
+                        const int oj = ok ? (mr + j) * sAm + kr * sAk : 0;
+                        va[4 * g + j] = ok ? pa[(unsigned)oj] : 0.f;
+                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? py[(unsigned)oj] : 0.f;
                     }
                 }
             }
@@ -485,9 +490,11 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             } else {
                 const int kk = kt + bkl0 + 16 * g;
                 const bool kok = kk < k1;
-                const int o = q.boff[g] + kt * sBk;
+                const int clip = (fr && kok) ? kk / fr : 0, kr = fr ? kk - clip * fr : kk;
+                const gcptr pb = baseB + clip * bcs;
+                const int o = q.boff[g] + kr * sBk;
                 if (q.bvec[g] & kok) {
-                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (unsigned)o);
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(pb + (unsigned)o);
                     vb[4 * g] = t[0]; vb[4 * g + 1] = t[1]; vb[4 * g + 2] = t[2]; vb[4 * g + 3] = t[3];
                 } else {
                     const int nr = q.tn * MF_BN + brow0;
@@ -495,7 +502,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = kok & (nr + j < N);
                         const bool one = ok & (nr + j == b_ones);
-                        const float w = baseB[(unsigned)((ok & !one) ? kk * sBk + (nr + j) * sBn : 0)];
+                        const float w = pb[(unsigned)((ok & !one) ? kr * sBk + (nr + j) * sBn : 0)];
                         vb[4 * g + j] = one ? 1.f : (ok ? w : 0.f);
                     }
                 }

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, con
                                                             const float* up, const float* ut, int64_t nu, int nblk_u,
                                                             float* scratch, LossBatch lb) {
     __shared__ float red[4][NP_SUMS];
+    __shared__ float tile_p[256 * 5], tile_t[256 * 5];
     {
         const int64_t k = blockIdx.y;
         pp += k * lb.ws; pt += k * lb.ext0; up += k * lb.ws; ut += k * lb.ext1; scratch += k * lb.tmp;
@@ -65,9 +66,22 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, con
     float acc[NP_SUMS];
 #pragma unroll
     for (int k = 0; k < NP_SUMS; ++k) acc[k] = 0.f;
-    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
-        if (pitched) note_terms<5>(pp + i * 5, pt + i * 5, acc);
-        else note_terms<2>(up + i * 2, ut + i * 2, acc);
+    // a tile of 256 positions is staged through LDS with unit-stride loads (a lane's own 5-float record is a stride-5
+    // access: every wave load touched 5 x the cache lines it used); lane <-> position and the order of a lane's sums are unchanged
+    const int nf = pitched ? 5 : 2;
+    const float* P = pitched ? pp : up;
+    const float* T = pitched ? pt : ut;
+    for (int64_t base = (int64_t)blk * 256; base < n; base += (int64_t)nb * 256) {
+        const int rows = (int)(n - base < 256 ? n - base : 256), cnt = rows * nf;
+        const float* Pg = P + base * nf;
+        const float* Tg = T + base * nf;
+        for (int j = threadIdx.x; j < cnt; j += 256) { tile_p[j] = Pg[j]; tile_t[j] = Tg[j]; }
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            if (pitched) note_terms<5>(tile_p + threadIdx.x * 5, tile_t + threadIdx.x * 5, acc);
+            else note_terms<2>(tile_p + threadIdx.x * 2, tile_t + threadIdx.x * 2, acc);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < NP_SUMS; ++k) acc[k] = wave_sum(acc[k]);
@@ -244,6 +258,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
                                                        const float* saved, const float* gl,
                                                        float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb, float info_scale) {
     __shared__ float coef[N_TAPE_IN];
+    __shared__ float tile_p[256 * 5], tile_t[256 * 5];
     {
         const int64_t k = blockIdx.y;
         pp += k * lb.ws; pt += k * lb.ext0; up += k * lb.ws; ut += k * lb.ext1;
@@ -273,23 +288,34 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
         const float* c = coef + (pitched ? 0 : 7);
         const float cTP = c[0], cFP = c[1], cFN = c[2], cSEV = c[3], cSED = c[4];
         const float cBCE = pitched ? c[5] : 0.f;
-        for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
-            const float* p = P + i * nf;
-            const float* t = T + i * nf;
-            float* g = G + i * nf;
-            const float pv = p[1], tv = t[1];
-            const float m = tv > 0.f ? 1.f : 0.f;
-            // torch.min splits the gradient on ties; relu'(0) = 0
-            float gv = cTP * (pv < tv ? 1.f : (pv == tv ? 0.5f : 0.f));
-            gv += cFP * (pv - tv > 0.f ? 1.f : 0.f) - cFN * (tv - pv > 0.f ? 1.f : 0.f);
-            gv -= cSEV * 2.f * (tv - pv) * m;
-            g[1] = gv;
-            g[0] = cSED * 2.f * (p[0] - fminf(t[0], 6.f)) * (1.f / 36.f) * m;
-            if (pitched) {
+        // tiles of 256 positions through LDS: unit-stride loads and stores (see loss_partials_kernel)
+        for (int64_t base = (int64_t)blk * 256; base < n; base += (int64_t)nb * 256) {
+            const int rows = (int)(n - base < 256 ? n - base : 256), cnt = rows * nf;
+            const float* Pg = P + base * nf;
+            const float* Tg = T + base * nf;
+            float* Gg = G + base * nf;
+            for (int j = threadIdx.x; j < cnt; j += 256) { tile_p[j] = Pg[j]; tile_t[j] = Tg[j]; }
+            __syncthreads();
+            if ((int)threadIdx.x < rows) {
+                float* p = tile_p + threadIdx.x * nf;             // the gradient record replaces the prediction's
+                const float* t = tile_t + threadIdx.x * nf;
+                const float pv = p[1], tv = t[1], p0 = p[0];
+                const float m = tv > 0.f ? 1.f : 0.f;
+                // torch.min splits the gradient on ties; relu'(0) = 0
+                float gv = cTP * (pv < tv ? 1.f : (pv == tv ? 0.5f : 0.f));
+                gv += cFP * (pv - tv > 0.f ? 1.f : 0.f) - cFN * (tv - pv > 0.f ? 1.f : 0.f);
+                gv -= cSEV * 2.f * (tv - pv) * m;
+                p[1] = gv;
+                p[0] = cSED * 2.f * (p0 - fminf(t[0], 6.f)) * (1.f / 36.f) * m;
+                if (pitched) {
 #pragma unroll
-                for (int a = 2; a < 5; ++a)   // aten binary_cross_entropy_backward
-                    g[a] = cBCE * m * (p[a] - t[a]) / fmaxf((1.f - p[a]) * p[a], 1e-12f);
+                    for (int a = 2; a < 5; ++a)   // aten binary_cross_entropy_backward
+                        p[a] = cBCE * m * (p[a] - t[a]) / fmaxf((1.f - p[a]) * p[a], 1e-12f);
+                }
             }
+            __syncthreads();
+            for (int j = threadIdx.x; j < cnt; j += 256) Gg[j] = tile_p[j];
+            __syncthreads();
         }
     } else {
         const float ci = coef[13] * info_scale, cm = coef[14] * info_scale, cb = coef[15] * info_scale;

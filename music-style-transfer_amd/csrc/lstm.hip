@@ -252,6 +252,178 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
 #undef LSTM_LOAD
 }
 
+// ---- grouped flavour ---------------------------------------------------------------------------
+// Batched plans run thousands of short sequences through the same small LSTM (the beats LSTM: 64 sequences of 4 steps per
+// direction and clip, H = 64): with one sequence per workgroup, fetching the 64 KB of W_hh into registers cost more than the
+// four steps that used it.  Here a workgroup carries LSTM_NS sequences of the same LSTM: the weights are fetched once, every
+// step is a [4H x H] x [H x NS] product out of registers and LDS, and the gate math of the NS sequences spreads over
+// NS * H lanes.  Per sequence the arithmetic (and its order) is that of lstm_fwd_kernel<true> / lstm_bwd_kernel<true>.
+#define LSTM_NS 4
+__global__ __launch_bounds__(256) void lstm_fwd_group_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];
+    const int b0 = blockIdx.x * LSTM_NS;
+    if (b0 >= d.B) return;
+    const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
+    __shared__ float h_s[LSTM_NS][64];
+    __shared__ float z_s[LSTM_NS][256];
+    const float* whh = b.p[SP_PAR] + d.whh_off;
+    const float* zx = b.p[SP_WS] + d.zx_off;
+    float* ws = b.p[SP_WS];
+    float* tmp = b.p[SP_TMP];
+    float w[64];
+    if (tid < G) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float v = whh[(int64_t)tid * H + min(k, H - 1)];
+            w[k] = k < H ? v : 0.f;
+        }
+    }
+    // gate lane (sq, hh): hidden unit hh of the workgroup's sequence sq
+    const int sq = tid / H, hh = tid - sq * H, bi = b0 + sq;
+    const bool gate = sq < LSTM_NS && bi < d.B;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, zq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = d.reverse ? d.S - 1 : 0;
+    if (gate) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bias[q] = b.p[SP_PAR][d.bhh_off + q * H + hh];
+            zq[q] = zx[((int64_t)bi * d.S + s0) * G + q * H + hh];
+        }
+    }
+    (&h_s[0][0])[tid] = 0.f;
+    float c = 0.f;
+    for (int step = 0; step < d.S; ++step) {
+        const int s = d.reverse ? d.S - 1 - step : step;
+        const int64_t row = (int64_t)bi * d.S + s;
+        float zn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gate && step + 1 < d.S) {
+            const int sn = d.reverse ? s - 1 : s + 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zn[q] = zx[((int64_t)bi * d.S + sn) * G + q * H + hh];
+        }
+        MST_LDS_BARRIER();
+        if (tid < G) {
+            float z[LSTM_NS][4];
+#pragma unroll
+            for (int j = 0; j < LSTM_NS; ++j) { z[j][0] = 0.f; z[j][1] = 0.f; z[j][2] = 0.f; z[j][3] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {
+#pragma unroll
+                for (int j = 0; j < LSTM_NS; ++j) {
+                    z[j][0] = fmaf(w[k], h_s[j][k], z[j][0]); z[j][1] = fmaf(w[k + 1], h_s[j][k + 1], z[j][1]);
+                    z[j][2] = fmaf(w[k + 2], h_s[j][k + 2], z[j][2]); z[j][3] = fmaf(w[k + 3], h_s[j][k + 3], z[j][3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LSTM_NS; ++j) z_s[j][tid] = (z[j][0] + z[j][1]) + (z[j][2] + z[j][3]);
+        }
+        MST_LDS_BARRIER();
+        if (gate) {
+            const float* zr = z_s[sq];
+            const float ig = sigm(zr[hh] + zq[0] + bias[0]), fg = sigm(zr[H + hh] + zq[1] + bias[1]);
+            const float gg = tanh_fast(zr[2 * H + hh] + zq[2] + bias[2]), og = sigm(zr[3 * H + hh] + zq[3] + bias[3]);
+            tmp[d.hprev_off + row * H + hh] = h_s[sq][hh];
+            c = fg * c + ig * gg;
+            const float tc = tanh_fast(c);
+            const float h = og * tc;
+            tmp[d.tc_off + row * H + hh] = tc;
+            float* g = tmp + d.gates_off + row * G;
+            g[hh] = ig; g[H + hh] = fg; g[2 * H + hh] = gg; g[3 * H + hh] = og;
+            tmp[d.c_off + row * H + hh] = c;
+            ws[d.out_off + row * d.out_ld + hh] = h;
+            h_s[sq][hh] = h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void lstm_bwd_group_kernel(const LstmDesc* __restrict__ descs, Bases b) {
+    const LstmDesc d = descs[blockIdx.y];
+    const int b0 = blockIdx.x * LSTM_NS;
+    if (b0 >= d.B) return;
+    const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
+    __shared__ float dz_s[LSTM_NS][256 + 64];               // zero tail: lane (part, kk) reads rows part*H .. part*H + 63 unclamped
+    __shared__ float red_s[LSTM_NS][256];
+    const float* whh = b.p[SP_PAR] + d.whh_off;
+    const float* tmp = b.p[SP_TMP];
+    float* gr = b.p[SP_GRAD];
+    const int kk = tid % H, part = tid / H;                 // matvec lane (part, kk), as in lstm_bwd_kernel<true>
+    float w[64];
+    if (tid < G) {
+        // 32-bit lane offsets off the uniform base (4 H^2 floats): half the address registers of 64 flat pointers
+        const MST_GLOBAL_AS float* wb = (const MST_GLOBAL_AS float*)whh;
+        const unsigned o0 = (unsigned)(part * H) * (unsigned)H + (unsigned)kk;
+#pragma unroll
+        for (int jj = 0; jj < 64; ++jj) {
+            const float v = wb[o0 + (unsigned)(min(jj, H - 1) * H)];
+            w[jj] = jj < H ? v : 0.f;
+        }
+    }
+    const int sq = part, hh = kk, bi = b0 + sq;             // gate lane (sq, hh)
+    const bool gate = sq < LSTM_NS && bi < d.B;
+#pragma unroll
+    for (int j = 0; j < LSTM_NS; ++j) { red_s[j][tid] = 0.f; dz_s[j][tid] = 0.f; if (tid < 64) dz_s[j][256 + tid] = 0.f; }
+    float dc_next = 0.f;
+    float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load = [&](const int step, float* dst) {
+        const int s_ = d.reverse ? d.S - 1 - step : step;
+        const int sp_ = d.reverse ? s_ + 1 : s_ - 1;
+        const int64_t row_ = (int64_t)bi * d.S + s_;
+        const float* g_ = tmp + d.gates_off + row_ * G;
+        dst[0] = g_[hh]; dst[1] = g_[H + hh]; dst[2] = g_[2 * H + hh]; dst[3] = g_[3 * H + hh];
+        dst[4] = tmp[d.tc_off + row_ * H + hh];
+        dst[5] = step > 0 ? tmp[d.c_off + ((int64_t)bi * d.S + sp_) * H + hh] : 0.f;
+        dst[6] = gr[d.gout_off + row_ * d.out_ld + hh];
+    };
+    if (gate) load(d.S - 1, sv);
+    __syncthreads();
+    for (int step = d.S - 1; step >= 0; --step) {
+        const int s = d.reverse ? d.S - 1 - step : step;
+        const int64_t row = (int64_t)bi * d.S + s;
+        float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (gate) {
+            if (step > 0) load(step - 1, nx);
+            const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], tc = sv[4], cprev = sv[5];
+            const float* rr = red_s[sq];
+            const float dhr = (rr[hh] + rr[H + hh]) + (rr[2 * H + hh] + rr[3 * H + hh]);
+            const float dh = sv[6] + dhr;
+            const float dc = dc_next + dh * og * (1.f - tc * tc);
+            const float dzi = dc * gg * ig * (1.f - ig);
+            const float dzf = dc * cprev * fg * (1.f - fg);
+            const float dzg = dc * ig * (1.f - gg * gg);
+            const float dzo = dh * tc * og * (1.f - og);
+            dc_next = dc * fg;
+            float* dzr = dz_s[sq];
+            dzr[hh] = dzi; dzr[H + hh] = dzf; dzr[2 * H + hh] = dzg; dzr[3 * H + hh] = dzo;
+            float* gz = gr + d.gzx_off + row * G;
+            gz[hh] = dzi; gz[H + hh] = dzf; gz[2 * H + hh] = dzg; gz[3 * H + hh] = dzo;
+        }
+        MST_LDS_BARRIER();
+        if (tid < G) {          // the gate lanes' reads of red_s ended before the barrier above
+            // one sequence at a time (a real loop): fully unrolled over the sequences, the compiler fetched all 256 LDS
+            // operands of the step before the first FMA and spilled
+            const float* dzp = &dz_s[0][0] + part * H;
+#pragma unroll 1
+            for (int j = 0; j < LSTM_NS; ++j) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 64; jj += 4) {
+                    a0 = fmaf(w[jj], dzp[jj], a0); a1 = fmaf(w[jj + 1], dzp[jj + 1], a1);
+                    a2 = fmaf(w[jj + 2], dzp[jj + 2], a2); a3 = fmaf(w[jj + 3], dzp[jj + 3], a3);
+                }
+                red_s[j][tid] = (a0 + a1) + (a2 + a3);
+                dzp += 256 + 64;
+            }
+        }
+        if (gate) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) sv[q] = nx[q];
+        }
+        MST_LDS_BARRIER();
+    }
+}
+
 // ---- multi-workgroup flavour -------------------------------------------------------------------
 // One clip, H = 192 (StyleEncoder.bars_lstm), batch 1: a single workgroup streamed all 590 KB of W_hh from L2 every step
 // (one CU's L2 bandwidth: 5.4 us per step, 2 x 82 us per iteration — a fifth of the whole iteration).  Here LSTM_NB = 12
@@ -468,6 +640,13 @@ static int block_for(int maxH) {
     return t < 64 ? 64 : t;
 }
 
+// one workgroup per LSTM_NS sequences once a launch holds enough sequences to fill the chip several times over anyway
+#ifdef HIPSIM
+static bool lstm_grouped(int, int maxB) { return maxB >= 2 * LSTM_NS; }      // the interpreter's small cases take it too
+#else
+static bool lstm_grouped(int count, int maxB) { return maxB >= 2 * LSTM_NS && (int64_t)count * maxB >= 2048; }
+#endif
+
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
 #ifndef HIPSIM
@@ -476,7 +655,9 @@ int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, in
         return (int)hipGetLastError();
     }
 #endif
-    if (maxH <= 64)
+    if (maxH <= 64 && lstm_grouped(count, maxB))
+        hipLaunchKernelGGL(lstm_fwd_group_kernel, dim3((maxB + LSTM_NS - 1) / LSTM_NS, count), dim3(256), 0, s, dev_descs, b);
+    else if (maxH <= 64)
         hipLaunchKernelGGL((lstm_fwd_kernel<true>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
     else
         hipLaunchKernelGGL((lstm_fwd_kernel<false>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
@@ -491,7 +672,9 @@ int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, in
         return (int)hipGetLastError();
     }
 #endif
-    if (maxH <= 64)
+    if (maxH <= 64 && lstm_grouped(count, maxB))
+        hipLaunchKernelGGL(lstm_bwd_group_kernel, dim3((maxB + LSTM_NS - 1) / LSTM_NS, count), dim3(256), 0, s, dev_descs, b);
+    else if (maxH <= 64)
         hipLaunchKernelGGL((lstm_bwd_kernel<true>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);
     else
         hipLaunchKernelGGL((lstm_bwd_kernel<false>), dim3(maxB, count), dim3(block_for(maxH)), 0, s, dev_descs, b);

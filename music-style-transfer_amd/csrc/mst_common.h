@@ -96,6 +96,11 @@ struct GemmDesc {
     int32_t blk_begin;   // first workgroup of this member inside its (merged) launch
     int32_t kdsel;       // k-tile depth: 0 -> 32, 1 -> 64, 2 -> 128
     int32_t run;         // 64x64 tiling: consecutive output tiles one workgroup walks (same k-split); 0 / 1 = one tile
+    // Weight-gradient GEMMs of a batched plan fold the clips into the reduction: K = fold_rows * clips, reduction index
+    // k = (clip, row) reads A at A.off + clip * acs (+ acs2 for the activation) + row ..., B at B.off + clip * bcs + row ...
+    // One GEMM instead of one per clip: no k-tile padding at short sequences, clips x fewer slab rows to reduce.
+    int32_t fold_rows;   // 0 = not folded
+    int64_t acs, acs2, bcs;
     Operand A, B;
     OutSpec out;
 };
@@ -206,7 +211,7 @@ int launch_combine_phase(const CombineDesc* dev, int nblk, int which, Bases b, h
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
 // width > 0: the entry is a (count / width) x width block of a wider parameter matrix: element i lands at
 // dst + (i / width) * dst_ld + i % width (column blocks of a Linear whose input is a broadcast-concat, plan.hip linear_part)
-struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; int32_t width, dst_ld; };
+struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; int32_t width, dst_ld; int32_t single; /* 1: one slab for all clips (folded GEMM) */ };
 struct SlabBlock { int32_t entry, start; };   // one workgroup's 64-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)

@@ -196,7 +196,8 @@ struct SegIn { int space; int64_t off; int ld, width; int s[4]; bool grad; };
 enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_F, K_ME_B, K_PSA_F, K_PSA_B, K_LSTM_T, K_ROW_F, K_ROW_B,
        K_ME_SQ, K_ME_RED,
        // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
-       K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG };
+       K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG,
+       K_GEMM_FOLD };      // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
 struct Step { int kind, first, count, a, b, stage; };
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
@@ -309,6 +310,25 @@ struct mst_plan {
     // weight-gradient GEMMs reduce over rows.  One clip per launch (latency-bound): one k-split per 256 rows (2 k-tiles),
     // capped at 64 slabs, for workgroup count.  Batched plans get their parallelism from the clips, so a split covers
     // up to 2048 rows (64 MFMA k-tiles, at 64 clips) and the slab traffic of the deferred reduction shrinks accordingly.
+    // batched plans on the 64x64 tiling fold the clips into the reduction of their weight-gradient GEMMs (GemmDesc.fold_rows)
+    bool folds_clips() const { return K() > 1 && (opt.gemm_tile == 64 || (opt.gemm_tile == 0 && K() >= 6)); }
+    // k-splits of a folded reduction: enough (tile, split) workgroups to fill the chip about three times over, at least
+    // 128 reduction rows per split; the slab a split writes is one weight gradient, so many splits of a small weight are cheap
+    int fold_splits(int rows, int M, int N, int members) const {
+        const int64_t kt = (int64_t)rows * K();
+        const int64_t t = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * members;      // `members` like GEMMs share the launch
+        int64_t s = (768 + t - 1) / t;
+        const int64_t kmax = kt / 128;
+        if (s > kmax) s = kmax;
+        while (s > 1 && (int64_t)M * N * s > (int64_t)4 << 20) --s;      // <= 16 MB of slab per weight
+        s = s < 1 ? 1 : (s > 256 ? 256 : s);
+        const int64_t chunk = ((kt + s - 1) / s + 31) / 32 * 32;          // the kernel rounds a split's share to whole k-tiles:
+        return (int)((kt + chunk - 1) / chunk);                           // no split may come out empty (its slab would stay unwritten)
+    }
+    // turns the weight-gradient GEMM `w` (built for one clip, reduction over `rows`) into the folded form
+    void fold(GemmDesc& w, int rows, int members = 1) {
+        w.fold_rows = rows; w.K = rows * K(); w.ksplit = fold_splits(rows, w.M, w.N, members);       // the clip strides are set at schedule time
+    }
     int splits_for(int rows) const {
         const int per = 32 * K() < 256 ? 256 : (32 * K() > 2048 ? 2048 : 32 * K());
         int s = (rows + per - 1) / per;
@@ -400,14 +420,18 @@ struct mst_plan {
             w.A.kind = OPK_ACTGRAD; w.A.space = SP_GRAD; w.A.off = out.off; w.A.space2 = SP_WS; w.A.off2 = out.off;
             w.A.ld = out.ld; w.A.act = act; w.A.transposed = 1; w.A.kfast = 0;
             w.B.kind = OPK_DENSE; w.B.space = space; w.B.off = xoff; w.B.si = xld; w.B.sj = 1; w.B.ones_at = K; w.B.kfast = 0;
+            const bool fd = folds_clips();
+            if (fd) fold(w, rows);
             const int64_t stride = (int64_t)N * K + N;
             const int64_t slab = tmp(stride * w.ksplit);
             w.out.kind = pb ? OUT_PERMW_SLAB : OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride;
             w.out.wcols = K; w.out.pb = pb; w.out.pc = pc; w.out.bias_space = -1;
-            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(N, K + 1), w.ksplit});
+            op.bwd.push_back(Step{fd ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(N, K + 1), w.ksplit});
             gemms.push_back(w);
-            slabs[stage_idx(stage)].push_back(SlabEntry{woff, slab, stride, N * K, w.ksplit});
-            slabs[stage_idx(stage)].push_back(SlabEntry{boff, slab + (int64_t)N * K, stride, N, w.ksplit});
+            SlabEntry e1{woff, slab, stride, N * K, w.ksplit}, e2{boff, slab + (int64_t)N * K, stride, N, w.ksplit};
+            e1.single = e2.single = fd ? 1 : 0;
+            slabs[stage_idx(stage)].push_back(e1);
+            slabs[stage_idx(stage)].push_back(e2);
         }
         if (xgrad) {
             if (pb || space != SP_WS) { err = MST_ERR_UNSUPPORTED; }
@@ -494,6 +518,8 @@ struct mst_plan {
             GemmDesc w{}; w.M = 4 * H; w.N = H + 1; w.K = (int)n; w.ksplit = splits_for((int)n);
             w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = zxs[i].off; w.A.si = 1; w.A.sj = 4 * H; w.A.ones_at = -1; w.A.kfast = 0;
             w.B.kind = OPK_DENSE; w.B.space = SP_TMP; w.B.off = l.hprev_off; w.B.si = H; w.B.sj = 1; w.B.ones_at = H; w.B.kfast = 0;
+            const bool fd = folds_clips();
+            if (fd) fold(w, (int)n, (int)specs.size());
             const int64_t stride = (int64_t)4 * H * H + 4 * H;
             const int64_t slab = tmp(stride * w.ksplit);
             w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = H;
@@ -501,15 +527,17 @@ struct mst_plan {
             hh.push_back(w);
             if (tiles(w.M, w.N) > maxTiles) maxTiles = tiles(w.M, w.N);
             if (w.ksplit > maxSplit) maxSplit = w.ksplit;
-            slabs[stage_idx(stage)].push_back(SlabEntry{whh, slab, stride, 4 * H * H, w.ksplit});
-            slabs[stage_idx(stage)].push_back(SlabEntry{bhh, slab + (int64_t)4 * H * H, stride, 4 * H, w.ksplit});
+            SlabEntry e1{whh, slab, stride, 4 * H * H, w.ksplit}, e2{bhh, slab + (int64_t)4 * H * H, stride, 4 * H, w.ksplit};
+            e1.single = e2.single = fd ? 1 : 0;
+            slabs[stage_idx(stage)].push_back(e1);
+            slabs[stage_idx(stage)].push_back(e2);
         }
         if (maxH > 64 && minH <= 64) err = MST_ERR_UNSUPPORTED;       // one register/L2 flavour per launch
         const int cnt = (int)specs.size();
         if (maxH > 64) op.fwd.push_back(Step{K_LSTM_T, first, cnt, 0, maxH});
         op.fwd.push_back(Step{K_LSTM_F, first, cnt, maxB, maxH});
         op.bwd.push_back(Step{K_LSTM_B, first, cnt, maxB, maxH});
-        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), cnt, maxTiles, maxSplit});
+        op.bwd.push_back(Step{folds_clips() ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), cnt, maxTiles, maxSplit});
         for (auto& w : hh) gemms.push_back(w);
         ops.push_back(op);
     }
@@ -562,14 +590,16 @@ struct mst_plan {
             GemmDesc w{}; w.M = N; w.N = kb + (pbias ? 1 : 0); w.K = rows; w.ksplit = splits_for(rows);
             w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = out.off + col0; w.A.si = 1; w.A.sj = out.ld; w.A.ones_at = -1; w.A.kfast = 0;
             w.B.kind = OPK_DENSE; w.B.space = SP_WS; w.B.off = x.off; w.B.si = x.ld; w.B.sj = 1; w.B.ones_at = pbias ? kb : -1; w.B.kfast = 0;
+            const bool fd = folds_clips();
+            if (fd) fold(w, rows);
             const int64_t stride = (int64_t)N * kb + N;
             const int64_t slab = tmp(stride * w.ksplit);
             w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = kb; w.out.bias_space = -1;
-            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
+            op.bwd.push_back(Step{fd ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
             gemms.push_back(w);
-            SlabEntry e{woff, slab, stride, N * kb, w.ksplit}; e.width = kb; e.dst_ld = Kfull;
+            SlabEntry e{woff, slab, stride, N * kb, w.ksplit}; e.width = kb; e.dst_ld = Kfull; e.single = fd ? 1 : 0;
             slabs[stage_idx(stage)].push_back(e);
-            if (pbias) slabs[stage_idx(stage)].push_back(SlabEntry{pt.off(bname), slab + (int64_t)N * kb, stride, N, w.ksplit});
+            if (pbias) { SlabEntry eb{pt.off(bname), slab + (int64_t)N * kb, stride, N, w.ksplit}; eb.single = fd ? 1 : 0; slabs[stage_idx(stage)].push_back(eb); }
         }
         if (xgrad) {
             GemmDesc a{}; a.M = rows; a.N = kb; a.K = N; a.ksplit = 1;
@@ -980,10 +1010,11 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
     const std::vector<RowLinDesc>& rowlins = scheduled ? s_rowlins : this->rowlins;
     for (int i = 0; i < s.count; ++i) {
         switch (s.kind) {
-        case K_GEMM: {
+        case K_GEMM: case K_GEMM_FOLD: {
             const GemmDesc& g = gemms[s.first + i];
-            operand_acc(v, g.A, g.M, g.K, -1);
-            operand_acc(v, g.B, g.K, g.N, g.B.ones_at);
+            const int gk = g.fold_rows ? g.fold_rows : g.K;      // a folded reduction touches, per clip, what one clip's would
+            operand_acc(v, g.A, g.M, gk, -1);
+            operand_acc(v, g.B, gk, g.N, g.B.ones_at);
             const OutSpec& o = g.out;
             if (o.bias_space >= 0) acc_add(v, o.bias_space, o.bias_off, g.N, false);       // a bias row that is an activation (linear_part)
             if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
@@ -1186,13 +1217,13 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
         for (int i = 0; i < n; ++i) {
             if (done[i] || level[i] != lv) continue;
             const Step& s0 = seq[i];
-            const bool mergeable = !opt.no_merge && (s0.kind == K_GEMM || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
+            const bool mergeable = !opt.no_merge && (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
                                    s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
             Step m = s0; m.count = 0;
             const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
             const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B || (s0.kind >= K_COMB_F1 && s0.kind <= K_COMB_B2);
             const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B || s0.kind == K_ME_SQ || s0.kind == K_ME_RED;
-            if (s0.kind == K_GEMM) m.first = (int)s_gemms.size();
+            if (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD) m.first = (int)s_gemms.size();
             else if (s0.kind == K_GATHER) m.first = (int)s_gathers.size();
             else if (s0.kind == K_SEGRED) m.first = (int)s_segreds.size();
             else if (is_lstm) m.first = (int)s_lstms.size();
@@ -1215,11 +1246,14 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             }
             // clip-major replication: clip k's copy of every member, relocated to clip k's workspace slices.
             // The W_hh transpose reads parameters only, so it runs once for all clips.
-            const int copies = s0.kind == K_LSTM_T ? 1 : K();
+            const int copies = (s0.kind == K_LSTM_T || s0.kind == K_GEMM_FOLD) ? 1 : K();
             for (int k = 0; k < copies; ++k) {
                 for (int idx : members) {
-                    if (s0.kind == K_GEMM) {
+                    if (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD) {
                         GemmDesc g = reloc(gemms[idx], k); g.variant = gemm_variant(g);
+                        if (g.fold_rows) {          // arena sizes are final now: clip strides of the folded reduction
+                            g.acs = shift(g.A.space, 1); g.acs2 = g.A.kind == OPK_ACTGRAD ? shift(g.A.space2, 1) : 0; g.bcs = shift(g.B.space, 1);
+                        }
                         const int kr = (g.K + g.ksplit - 1) / g.ksplit;
                         g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2);
                         // tiles per workgroup (64x64 tiling): measured on MI355X at 64 clips per launch, runs of 2 / 4 / 8 tiles
@@ -1238,7 +1272,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 }
             }
             m.count = (int)members.size() * copies;
-            if (m.kind == K_GEMM) {      // flat grid: a clip's block range concatenates its members' (tile, k-split) workgroups
+            if (m.kind == K_GEMM || m.kind == K_GEMM_FOLD) {      // flat grid: a clip's block range concatenates its members' (tile, k-split) workgroups
                 const int nm = (int)members.size();
                 int total = 0;
                 for (int q = 0; q < nm; ++q) {
@@ -1297,8 +1331,8 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
     const int copies = K();
     for (size_t si = begin; si < list.size(); ++si) {
         Step& m = list[si];
-        const bool plain = m.kind >= K_COPY_F;               // indexes an unscheduled (one-clip) descriptor vector
-        const int nm = m.kind == K_GEMM ? m.b : (plain ? m.count : m.count / copies);
+        const bool plain = m.kind >= K_COPY_F && m.kind != K_GEMM_FOLD;   // indexes an unscheduled (one-clip) descriptor vector
+        const int nm = (m.kind == K_GEMM || m.kind == K_GEMM_FOLD) ? m.b : (plain ? m.count : m.count / copies);
         for (int q = 0; q < nm; ++q) {
             std::vector<Acc> acc;
             Step one = m; one.first = m.first + q; one.count = 1;
@@ -1398,7 +1432,7 @@ int mst_plan::upload() {
     for (int st = 0; st < 3; ++st) e |= up(zero_stage[st], &d_zero_stage[st]);
     e |= up(zero_all, &d_zero_all);
     for (int s = 0; s < 3; ++s) {
-        for (auto& ent : slabs[s]) { ent.reps = K(); ent.rep_stride = tmp_top; }
+        for (auto& ent : slabs[s]) { ent.reps = ent.single ? 1 : K(); ent.rep_stride = tmp_top; }
         e |= up(slabs[s], &d_slabs[s]);
         for (size_t i = 0; i < slabs[s].size(); ++i)
             for (int st = 0; st < slabs[s][i].count; st += 64) slab_blocks[s].push_back(SlabBlock{(int)i, st});
@@ -1489,7 +1523,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
+    case K_GEMM: case K_GEMM_FOLD: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count / p->K(), s.a, p->K(), s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, p->s_lstms[s.first].multi, b, st);
@@ -1670,7 +1704,7 @@ extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float
 static void step_cost(const mst_plan* p, const Step& s, double* flops, double* bytes) {
     double f = 0, b = 0;
     switch (s.kind) {
-    case K_GEMM:
+    case K_GEMM: case K_GEMM_FOLD:
         for (int i = 0; i < s.count; ++i) {
             const GemmDesc& g = p->s_gemms[s.first + i];
             f += 2.0 * g.M * g.N * g.K;
@@ -1759,7 +1793,7 @@ extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t b
     for (const Step* s : steps) {
         int32_t* o = info + 5 * idx++;
         o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count;
-        if (s->kind == K_GEMM) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
+        if (s->kind == K_GEMM || s->kind == K_GEMM_FOLD) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
         else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
         else if (s->kind == K_GATHER) { const GatherDesc& g = p->s_gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
         else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->s_segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
@@ -1787,7 +1821,7 @@ extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t 
         hipEventSynchronize(e1);
         float t = 0.f;
         hipEventElapsedTime(&t, e0, e1);
-        ms[idx] = t / reps; kind[idx] = s->kind;
+        ms[idx] = t / reps; kind[idx] = s->kind == K_GEMM_FOLD ? K_GEMM : s->kind;      // same kernel
         step_cost(p, *s, &flops[idx], &bytes[idx]);
         ++idx;
     }
