@@ -177,19 +177,30 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(const float* scratch, int
     // partial rows hold 7 sums {TP FP FN SEvel SEdur BCE Nmask}; tape inputs 0..6 are the pitched tensor's,
     // 7..12 the unpitched tensor's {TP FP FN SEvel SEdur Nmask}.  Lanes stride over the per-workgroup partials,
     // then a fixed-order wave reduction (the tail is one 64-lane wave).
+    // A lane takes whole 8-float partial rows (two 16-byte loads per row, both tensors' loops in flight together) instead of
+    // fourteen dependent strided passes; per lane and per sum the order over q, and the wave reduction, are the same.
+    {
+        float sp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, su[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        typedef float row4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte load, 4-byte alignment suffices
+        const row4* rp = reinterpret_cast<const row4*>(scratch);
+        const row4* ru = reinterpret_cast<const row4*>(scratch + LOSS_MAXBLK * 8);
+        const int nbu = has_u ? nblk_u : 0;
+        for (int q = tid; q < nblk_p; q += 64) {
+            const row4 x = rp[2 * q], y = rp[2 * q + 1];
+            sp[0] += x.x; sp[1] += x.y; sp[2] += x.z; sp[3] += x.w; sp[4] += y.x; sp[5] += y.y; sp[6] += y.z;
+        }
+        for (int q = tid; q < nbu; q += 64) {
+            const row4 x = ru[2 * q], y = ru[2 * q + 1];
+            su[0] += x.x; su[1] += x.y; su[2] += x.z; su[3] += x.w; su[4] += y.x; su[5] += y.y; su[6] += y.z;
+        }
 #pragma unroll
-    for (int k = 0; k < 14; ++k) {
-        const bool pitched = k < 7;
-        const int kk = pitched ? k : k - 7;
-        const float* src = scratch + (pitched ? 0 : LOSS_MAXBLK * 8);
-        const int nb = pitched ? nblk_p : (has_u ? nblk_u : 0);
-        float s = 0.f;
-        for (int q = tid; q < nb; q += 64) s += src[q * 8 + kk];
-        s = wave_sum(s);
+        for (int k = 0; k < 7; ++k) { sp[k] = wave_sum(sp[k]); su[k] = wave_sum(su[k]); }
         if (tid == 0) {
-            if (pitched) sums[kk] = s;
-            else if (kk < 5) sums[7 + kk] = s;
-            else if (kk == 6) sums[12] = s;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sums[k] = sp[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sums[7 + k] = su[k];
+            sums[12] = su[6];
         }
     }
     // instruments: BCE-with-logits, mean over ni (style/model.py:903)

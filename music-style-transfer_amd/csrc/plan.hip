@@ -239,6 +239,7 @@ struct mst_plan {
     struct Xchg { int space; int64_t off; int32_t len; };
     std::vector<CopyDesc> copies; std::vector<FoldDesc> folds; std::vector<Xchg> xchgs;
     CopyDesc* d_copies = nullptr; FoldDesc* d_folds = nullptr;
+    bool tags_in_zero = false;             // zero_all also clears the multi-workgroup LSTM's exchange tags
     std::vector<ZeroChunk> zero_fwd; ZeroChunk* d_zero_fwd = nullptr;      // activation ranges cleared before a tiled forward
     int64_t loss_sum_off = 0;                                               // [SP_TMP] 16 floats: the loss partial sums, folded
     int loss_fold[2] = {-1, -1};
@@ -1385,6 +1386,11 @@ void mst_plan::schedule() {
     };
     for (int st = 0; st < 3; ++st) chunks(zs, 1 << st, zero_stage[st]);
     chunks(za, MST_STAGE_ALL, zero_all);
+    // one-clip plans: the exchange tags of the multi-workgroup LSTM ride on the same launch (the scratch arena follows the
+    // gradient arena, so a chunk can address it); mst_train_iteration then skips the separate clear
+    if (K() == 1)
+        for (const LstmDesc& l : lstms)
+            if (l.multi) { zero_all.push_back(ZeroChunk{act_top + l.xch_off, (int32_t)(2 * (2 * l.H + 8 * l.H)), 0}); tags_in_zero = true; }
     if (!tiled()) return;
     // ---- one train iteration of a tiled plan as phases that end at an exchange
     {   // loss partial sums (7 per note tensor, one row per workgroup) -> 16 floats that the ranks sum
@@ -1553,9 +1559,10 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
 }
 
 // Run one pass (a scheduled list filtered by stage) on the caller's stream.
-static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b, hipStream_t main) {
+static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b, hipStream_t main, bool tags_cleared = false) {
     for (auto& s : list) {
         if (!(s.stage & mask)) continue;
+        if (tags_cleared && s.kind == K_LSTM_T && p->s_lstms[s.first].multi) continue;      // its only job was the clear
         int e = run_step(p, s, b, main);
         if (e) return e < 0 ? e : MST_ERR_LAUNCH;
     }
@@ -1606,7 +1613,8 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     hipStream_t st = (hipStream_t)stream;
     int e = mst_zero_grads(p, MST_STAGE_ALL, ws, stream);
     if (e) return e;
-    e = mst_forward(p, MST_STAGE_ALL, params, ws, pitched, unpitched, stream);
+    if (p->d.has_unpitched && !unpitched) return MST_ERR_ARG;
+    e = run_pass(p, p->list(MST_STAGE_ALL, 0), MST_STAGE_ALL, make_bases(p, params, nullptr, ws, pitched, unpitched), st, p->tags_in_zero);
     if (e) return e;
     const bool U = p->d.has_unpitched != 0;
     const int K = p->K();
