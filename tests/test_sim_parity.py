@@ -12,8 +12,9 @@ def test_golden_small(name):
     pc.golden_small(sim_native(), 'cpu', name)
 
 
-@pytest.mark.parametrize('C,R,T,unp', [(1, 1, 1, True), (3, 2, 3, False), (2, 5, 1, True)])
+@pytest.mark.parametrize('C,R,T,unp', [(1, 1, 1, True), (3, 2, 3, False), (2, 5, 1, True), (3, 3, 2, True)])
 def test_oracle_small_widths_ragged_shapes(C, R, T, unp):
+    # C * R >= 8 sequences per beat LSTM take the grouped kernels (4 sequences per workgroup) on the interpreter: 10 = 4 + 4 + 2, 9 = 4 + 4 + 1
     pc.oracle_case(sim_native(), 'cpu', pc.SMALL, C, R, T, unp, density=0.05, check_bitwise=True)
 
 

@@ -26,13 +26,26 @@ for k in ('gemm_kernel', 'gemm_mfma_kernel'):
     if k in fetch:
         fb, wb = fetch[k]['avg_kb_per_launch'] * 1024, write.get(k, dict(avg_kb_per_launch=0))['avg_kb_per_launch'] * 1024
         out[k] = dict(fetch_bytes_per_launch=fb, write_bytes_per_launch=wb, hbm_bytes_per_launch=fb + wb)
-# whole-pass traffic: every kernel's bytes summed, per training iteration (sys.argv[5] = iterations the command ran, warm-up included)
+# whole-pass traffic: every kernel's bytes summed, per training iteration.  Kernels that only run while the benchmark sets up
+# (torch's fills of the freshly allocated workspace, runtime buffer copies of the uploads) are listed separately: they are
+# not part of an iteration and would otherwise be spread over however few iterations a counter run happens to have
+def is_setup(name):
+    return name.startswith('void at::native') or name.startswith('__amd_rocclr')
+
+
+def per_iteration(fetch, write, clips):
+    # passes = launches of loss_tail_kernel (one per pass, nothing else launches it)
+    iters = float(clips) * fetch['loss_tail_kernel']['launches']
+    def total(tab, setup):
+        return sum(v['launches'] * v['avg_kb_per_launch'] for k, v in tab.items() if is_setup(k) == setup) * 1024
+    f, w = total(fetch, False) / iters, total(write, False) / iters
+    return dict(iterations=iters, fetch_bytes=f, write_bytes=w, hbm_bytes=f + w,
+                setup_bytes_whole_run=total(fetch, True) + total(write, True),
+                note='all kernels of the timed loop (model, loss, optimizer) / iterations; raw counters; setup_bytes_whole_run = '
+                     'one-time fills / uploads before the loop (torch fill kernels, runtime copies), not included')
+
+
 if len(sys.argv) > 5:
-    # sys.argv[5] = clips per pass; passes = launches of loss_tail_kernel (one per pass, nothing else launches it)
-    iters = float(sys.argv[5]) * fetch['loss_tail_kernel']['launches']
-    tot_f = sum(v['launches'] * v['avg_kb_per_launch'] for v in fetch.values()) * 1024 / iters
-    tot_w = sum(v['launches'] * v['avg_kb_per_launch'] for v in write.values()) * 1024 / iters
-    out['per_iteration'] = dict(iterations=iters, fetch_bytes=tot_f, write_bytes=tot_w, hbm_bytes=tot_f + tot_w,
-                                note='all kernels of the run (model, loss, optimizer, copies) / iterations; raw counters')
+    out['per_iteration'] = per_iteration(fetch, write, sys.argv[5])
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print({k: out[k] for k in out if k.startswith('gemm')})
