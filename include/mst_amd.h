@@ -184,6 +184,9 @@ int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_
  * 11 lstm weight transpose, 12/13 row-wise tiny Linear fwd/bwd. */
 int32_t mst_plan_step_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
 int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 5 ints per step */);
+/* (new) instrumentation: the members of GEMM launch step `step` of a pass, one clip's worth, 6 values each:
+ * {M, N, K, k-splits, folded rows per clip (0 = not folded), workgroups}.  Returns the member count (<= cap). */
+int32_t mst_plan_step_gemms(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t step, int32_t* out, int32_t cap);
 int32_t mst_plan_time_steps(const mst_plan* p, int32_t stage_mask, int32_t backward, const float* params,
                             float* gparams, float* ws, const float* pitched, const float* unpitched,
                             mst_stream stream, int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes);

@@ -390,7 +390,6 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     const int k1 = min(d.K, k0 + kchunk);
     if (k0 >= k1 || t_begin >= t_end) return;
     const int wv = tid >> 6, lane = tid & 63;
-    const int wm = wv >> 1, wn = wv & 1;
     const gcptr baseA = (gcptr)(b.p[d.A.space] + d.A.off);
     const gcptr baseY = AK == OPK_ACTGRAD ? (gcptr)(b.p[d.A.space2] + d.A.off2) : baseA;
     const gcptr baseB = (gcptr)(b.p[d.B.space] + d.B.off);
@@ -544,17 +543,50 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             if (last_k) geo_of(nt, gl);
             issue(gl, nkt);                  // flies under this step's MFMAs, the epilogue and the barrier
         }
+        // Skinny tiles (<= 32 live rows and / or columns: weight gradients of 16-wide layers, N = 16 projections) used to
+        // run full 32x32 MFMAs on all four waves, two or three of them on padding.  The waves a tile does not need for
+        // blocks take a slice of the k-tile instead: nblk = live 32x32 blocks, wave w -> block w % nblk, k-slice w / nblk;
+        // the slices' accumulators meet in LDS at the tile's last k-tile, summed in slice order.
+        const int mb = (M - tm * MF_BM > 32) ? 2 : 1, nb = (N - tn * MF_BN > 32) ? 2 : 1, nblk = mb * nb;
+        const int blk = wv % nblk, ks = wv / nblk, nsl = 4 / nblk;
+        const int bm = blk / nb, bn = blk - bm * nb;
+        {
+            const int per = (MF_KD / 2) / nsl, kk0 = ks * per;
+            const int live = (min(k1 - kt, MF_KD) + 1) >> 1;         // k pairs of this k-tile that hold data (K = 10 -> 5 of 16)
+            if (nsl == 1 && live == MF_KD / 2) {
 #pragma unroll
-        for (int kk = 0; kk < MF_KD / 2; ++kk) {
-            const int k = kk * 2 + (lane >> 5);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][wm * 32 + (lane & 31)], Bs[k][wn * 32 + (lane & 31)], acc, 0, 0, 0);
+                for (int kk = 0; kk < MF_KD / 2; ++kk) {
+                    const int k = kk * 2 + (lane >> 5);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][bm * 32 + (lane & 31)], Bs[k][bn * 32 + (lane & 31)], acc, 0, 0, 0);
+                }
+            } else {
+                for (int kk = kk0; kk < min(kk0 + per, live); ++kk) {
+                    const int k = kk * 2 + (lane >> 5);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][bm * 32 + (lane & 31)], Bs[k][bn * 32 + (lane & 31)], acc, 0, 0, 0);
+                }
+            }
         }
         if (last_k) {
-            const int n = tn * MF_BN + wn * 32 + (lane & 31);
-            if ((tm * MF_BM + wm * 32 < M) & (tn * MF_BN + wn * 32 < N)) {
+            if (nsl > 1) {                                   // workgroup-uniform (tile geometry)
+                float* part = smem + buf * 2 * TILE_F;       // this step's tiles: free once every wave is past its MFMAs
+                MST_LDS_BARRIER();
+                if (ks > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[((ks - 1) * nblk + blk) * 1024 + r * 64 + lane] = acc[r];
+                }
+                MST_LDS_BARRIER();
+                if (ks == 0) {
+                    for (int q = 0; q < nsl - 1; ++q) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += part[(q * nblk + blk) * 1024 + r * 64 + lane];
+                    }
+                }
+            }
+            const int n = tn * MF_BN + bn * 32 + (lane & 31);
+            if ((ks == 0) & (tm * MF_BM + bm * 32 < M) & (tn * MF_BN + bn * 32 < N)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = tm * MF_BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int m = tm * MF_BM + bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (m < M && n < N) store_out<OK>(d, cbase, bias, m, n, split, acc[r]);
                 }
             }

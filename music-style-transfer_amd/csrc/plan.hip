@@ -1810,6 +1810,25 @@ extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t b
     return idx;
 }
 
+// members of GEMM step i of a pass, one clip's worth: {M, N, K, ksplit, fold_rows, workgroups} each (tools/step_profile.py)
+extern "C" int32_t mst_plan_step_gemms(const mst_plan* p, int32_t mask, int32_t backward, int32_t step, int32_t* out, int32_t cap) {
+    if (!p || !out) return MST_ERR_ARG;
+    int idx = 0;
+    for (auto& s : p->list(mask, backward)) {
+        if (!(s.stage & mask)) continue;
+        if (idx++ != step) continue;
+        if (s.kind != K_GEMM && s.kind != K_GEMM_FOLD) return 0;
+        int n = 0;
+        for (int q = 0; q < s.b && n < cap; ++q, ++n) {
+            const GemmDesc& g = p->s_gemms[s.first + q];
+            int32_t* o = out + 6 * n;
+            o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; o[4] = g.fold_rows; o[5] = gemm_blocks(g, p->mfma);
+        }
+        return n;
+    }
+    return MST_ERR_ARG;
+}
+
 extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t backward, const float* params, float* gparams,
                                        float* ws, const float* pitched, const float* unpitched, mst_stream stream,
                                        int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes) {

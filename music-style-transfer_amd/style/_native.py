@@ -87,6 +87,7 @@ _SIGS = {
     'mst_hard_output': (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P]),
     'mst_plan_step_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
     'mst_plan_step_info': (C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
+    'mst_plan_step_gemms': (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     'mst_plan_time_steps': (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     'mst_version': (C.c_char_p, []),
 }
@@ -255,6 +256,14 @@ class Plan:
         if got != n:
             check(got if got < 0 else -1, 'mst_plan_time_steps')
         return list(zip(kind.tolist(), ms.tolist(), fl.tolist(), by.tolist()))
+
+    def step_gemms(self, mask, backward, step, cap=2048):
+        """[(M, N, K, k_splits, fold_rows, workgroups)] of the members (one clip's worth) of GEMM launch step `step`."""
+        import numpy as np
+        out = np.zeros((cap, 6), np.int32)
+        n = self.lib.mst_plan_step_gemms(self.handle, mask, int(backward), step, out.ctypes.data, cap)
+        check(n if n < 0 else 0, 'mst_plan_step_gemms')
+        return [tuple(r) for r in out[:n].tolist()]
 
     def tiled_train_iteration(self, params, gparams, pitched, unpitched, losses=None, is_root=True, all_reduce=None):
         """One loop body of a clip whose bars are tiled over ranks (plan made with tile_r0 / tile_rows; `pitched` /
