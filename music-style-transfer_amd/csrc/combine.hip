@@ -173,11 +173,24 @@ __global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDes
     float acc[MC + 1];
 #pragma unroll
     for (int c = 0; c <= MC; ++c) acc[c] = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int64_t eo = elem_off(d, e);
+    // U elements per lane and trip, all their loads issued before the first use: one workgroup walks the whole site, and a
+    // trip per element was a chain of n / 256 dependent L2 round trips (16 us for 4096 elements).  Per lane the elements
+    // are still accumulated in ascending order.
+    constexpr int U = MC <= 4 ? 4 : 1;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * U) {
+        float v[U][MC];
 #pragma unroll
-        for (int c = 0; c < MC; ++c) {
-            if (c < d.Cn) { const float v = ws[d.x_off + (int64_t)c * d.cs + eo]; acc[c] = fmaf(v, v, acc[c]); }
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const bool ok = e < n;
+            const int64_t eo = elem_off(d, ok ? e : 0);
+#pragma unroll
+            for (int c = 0; c < MC; ++c) v[u][c] = (ok && c < d.Cn) ? ws[d.x_off + (int64_t)c * d.cs + eo] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int c = 0; c < MC; ++c) acc[c] = fmaf(v[u][c], v[u][c], acc[c]);
         }
     }
     block_sum_multi<MC>(acc, d.Cn, part, red);
@@ -191,11 +204,24 @@ __global__ __launch_bounds__(256) void combine_small_fwd_kernel(const CombineDes
     __syncthreads();
     if ((int)threadIdx.x <= d.Cn) tmp[d.stats_off + threadIdx.x] = (int)threadIdx.x < d.Cn ? nrm[threadIdx.x] : nrm[COMBINE_MAXC];
     const float S = nrm[COMBINE_MAXC];
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int64_t eo = elem_off(d, e);
-        float a = 0.f;
-        for (int c = 0; c < d.Cn; ++c) a += ws[d.x_off + (int64_t)c * d.cs + eo] * nrm[c];
-        ws[d.out_off + e] = a / S;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * U) {
+        float v[U][MC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const bool ok = e < n;
+            const int64_t eo = elem_off(d, ok ? e : 0);
+#pragma unroll
+            for (int c = 0; c < MC; ++c) v[u][c] = (ok && c < d.Cn) ? ws[d.x_off + (int64_t)c * d.cs + eo] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) if (c < d.Cn) a += v[u][c] * nrm[c];
+            if (e < n) ws[d.out_off + e] = a / S;
+        }
     }
 }
 
@@ -212,14 +238,27 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
     float acc[MC + 1];
 #pragma unroll
     for (int c = 0; c <= MC; ++c) acc[c] = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int64_t eo = elem_off(d, e);
-        const float g = gr[d.gout_off + e];
+    constexpr int U = MC <= 4 ? 4 : 1;                 // loads of U elements in flight per trip (see combine_small_fwd_kernel)
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * U) {
+        float v[U][MC], g[U], o[U];
 #pragma unroll
-        for (int c = 0; c < MC; ++c) {
-            if (c < d.Cn) acc[c] = fmaf(g, ws[d.x_off + (int64_t)c * d.cs + eo], acc[c]);
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const bool ok = e < n;
+            const int64_t eo = elem_off(d, ok ? e : 0);
+            g[u] = ok ? gr[d.gout_off + e] : 0.f;
+            o[u] = ok ? ws[d.out_off + e] : 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) v[u][c] = (ok && c < d.Cn) ? ws[d.x_off + (int64_t)c * d.cs + eo] : 0.f;
         }
-        acc[MC] = fmaf(g, ws[d.out_off + e], acc[MC]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e0 + 256 * u < n) {
+#pragma unroll
+                for (int c = 0; c < MC; ++c) if (c < d.Cn) acc[c] = fmaf(g[u], v[u][c], acc[c]);
+                acc[MC] = fmaf(g[u], o[u], acc[MC]);
+            }
+        }
     }
     float vals[MC + 1];
 #pragma unroll
@@ -232,15 +271,34 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
     __syncthreads();
     const float S = nc_s[d.Cn];
     const float bsum = coef[d.Cn];
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int64_t eo = elem_off(d, e);
-        const float g = gr[d.gout_off + e];
-        for (int c = 0; c < d.Cn; ++c) {
-            const float nc = nc_s[c];
-            const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
-            float* gx = gr + d.gx_off + (int64_t)c * d.cs + eo;
-            const float v = g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
-            *gx = d.first ? v : *gx + v;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * U) {
+        float x[U][MC], old[U][MC], g[U];
+        int64_t eo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const bool ok = e < n;
+            eo[u] = elem_off(d, ok ? e : 0);
+            g[u] = ok ? gr[d.gout_off + e] : 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) {
+                const bool okc = ok && c < d.Cn;
+                x[u][c] = okc ? ws[d.x_off + (int64_t)c * d.cs + eo[u]] : 0.f;
+                old[u][c] = (okc && !d.first) ? gr[d.gx_off + (int64_t)c * d.cs + eo[u]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e0 + 256 * u < n) {
+#pragma unroll
+                for (int c = 0; c < MC; ++c) {
+                    if (c < d.Cn) {
+                        const float nc = nc_s[c];
+                        const float v = g[u] * nc / S + ((coef[c] - bsum) / S) * (x[u][c] / nc);
+                        gr[d.gx_off + (int64_t)c * d.cs + eo[u]] = d.first ? v : old[u][c] + v;
+                    }
+                }
+            }
         }
     }
 }

@@ -402,7 +402,6 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     const int b_ones = d.B.ones_at;
     // clips folded into the reduction (weight gradients of a batched plan): k = (clip, row)
     const int fr = d.fold_rows;
-    const int64_t acs = d.acs, acs2 = d.acs2, bcs = d.bcs;
     // group geometry.  KF = 1 (k is unit stride): row = (tid >> 3) + 32 g, k = 4 (tid & 7) + j.
     //                  KF = 0 (row is unit stride): k = (tid >> 4) + 16 g, row = 4 (tid & 15) + j.
     const int arow0 = AKF ? (tid >> 3) : 4 * (tid & 15), akl0 = AKF ? 4 * (tid & 7) : (tid >> 4);
@@ -426,7 +425,26 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float va[8], vy[8], vb[8];
+    // folded reductions: (clip, row) of this lane's first k (group 0; both operands' row-contiguous groups sit at the same k)
+    // is carried from k-tile to k-tile — a 32-bit division per group and k-tile, plus 64-bit pointer arithmetic per clip
+    // stride, was most of what the waves of the skinny weight-gradient GEMMs issued.  Clip strides are 32-bit element
+    // offsets off the uniform base (the plan only folds when clips * stride fits)
+    const unsigned acs = (unsigned)d.acs, acs2 = (unsigned)d.acs2, bcs = (unsigned)d.bcs;
+    int f_kt = -(1 << 30), f_clip = 0, f_kr = 0;
+    auto fold_at = [&](const int kt, int (&clip)[2], int (&kr)[2]) {
+        const int kk = kt + (tid >> 4);
+        if (fr >= MF_KD && kt == f_kt + MF_KD) {
+            f_kr += MF_KD;
+            if (f_kr >= fr) { f_kr -= fr; ++f_clip; }
+        } else { f_clip = kk / fr; f_kr = kk - f_clip * fr; }
+        f_kt = kt;
+        clip[0] = f_clip; kr[0] = f_kr;
+        if (fr >= 16) { const bool w = f_kr + 16 >= fr; clip[1] = f_clip + (w ? 1 : 0); kr[1] = f_kr + 16 - (w ? fr : 0); }
+        else { clip[1] = (kk + 16) / fr; kr[1] = kk + 16 - clip[1] * fr; }
+    };
     auto issue = [&](const Geo& q, const int kt) {
+        int fclip[2] = {0, 0}, fkr[2] = {0, 0};
+        if ((!AKF || !BKF) && fr) fold_at(kt, fclip, fkr);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             // ---- A
@@ -451,14 +469,14 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             } else {
                 const int kk = kt + akl0 + 16 * g;
                 const bool kok = kk < k1;
-                const int clip = (fr && kok) ? kk / fr : 0, kr = fr ? kk - clip * fr : kk;
-                const gcptr pa = baseA + clip * acs, py = baseY + clip * acs2;
-                const int o = q.aoff[g] + kr * sAk;
+                const int kr = fr ? fkr[g] : kk;
+                const unsigned ca = kok ? (unsigned)fclip[g] * acs : 0u, cy = kok ? (unsigned)fclip[g] * acs2 : 0u;
+                const unsigned o = (unsigned)(q.aoff[g] + kr * sAk);
                 if (q.avec[g] & kok) {
-                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(pa + (unsigned)o);
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (o + ca));
                     va[4 * g] = t[0]; va[4 * g + 1] = t[1]; va[4 * g + 2] = t[2]; va[4 * g + 3] = t[3];
                     if constexpr (AK == OPK_ACTGRAD) {
-                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(py + (unsigned)o);
+                        const mf_f4u u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseY + (o + cy));
                         vy[4 * g] = u[0]; vy[4 * g + 1] = u[1]; vy[4 * g + 2] = u[2]; vy[4 * g + 3] = u[3];
                     }
                 } else {
@@ -466,9 +484,9 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = kok & (mr + j < M);
-                        const int oj = ok ? (mr + j) * sAm + kr * sAk : 0;
-                        va[4 * g + j] = ok ? pa[(unsigned)oj] : 0.f;
-                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? py[(unsigned)oj] : 0.f;
+                        const unsigned oj = ok ? (unsigned)((mr + j) * sAm + kr * sAk) : 0u;
+                        va[4 * g + j] = ok ? baseA[oj + ca] : 0.f;
+                        if constexpr (AK == OPK_ACTGRAD) vy[4 * g + j] = ok ? baseY[oj + cy] : 0.f;
                     }
                 }
             }
@@ -489,11 +507,11 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             } else {
                 const int kk = kt + bkl0 + 16 * g;
                 const bool kok = kk < k1;
-                const int clip = (fr && kok) ? kk / fr : 0, kr = fr ? kk - clip * fr : kk;
-                const gcptr pb = baseB + clip * bcs;
-                const int o = q.boff[g] + kr * sBk;
+                const int kr = fr ? fkr[g] : kk;
+                const unsigned cb = kok ? (unsigned)fclip[g] * bcs : 0u;
+                const unsigned o = (unsigned)(q.boff[g] + kr * sBk);
                 if (q.bvec[g] & kok) {
-                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(pb + (unsigned)o);
+                    const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (o + cb));
                     vb[4 * g] = t[0]; vb[4 * g + 1] = t[1]; vb[4 * g + 2] = t[2]; vb[4 * g + 3] = t[3];
                 } else {
                     const int nr = q.tn * MF_BN + brow0;
@@ -501,7 +519,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
                     for (int j = 0; j < 4; ++j) {
                         const bool ok = kok & (nr + j < N);
                         const bool one = ok & (nr + j == b_ones);
-                        const float w = pb[(unsigned)((ok & !one) ? kr * sBk + (nr + j) * sBn : 0)];
+                        const float w = baseB[(ok & !one) ? (unsigned)(kr * sBk + (nr + j) * sBn) + cb : 0u];
                         vb[4 * g + j] = one ? 1.f : (ok ? w : 0.f);
                     }
                 }

@@ -1254,6 +1254,8 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                         GemmDesc g = reloc(gemms[idx], k); g.variant = gemm_variant(g);
                         if (g.fold_rows) {          // arena sizes are final now: clip strides of the folded reduction
                             g.acs = shift(g.A.space, 1); g.acs2 = g.A.kind == OPK_ACTGRAD ? shift(g.A.space2, 1) : 0; g.bcs = shift(g.B.space, 1);
+                            // the loader adds clip * stride as a 32-bit element offset
+                            if ((uint64_t)std::max(g.acs, std::max(g.acs2, g.bcs)) * (uint64_t)K() > 0xFFFFFFFFull) err = MST_ERR_UNSUPPORTED;
                         }
                         const int kr = (g.K + g.ksplit - 1) / g.ksplit;
                         g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2);
