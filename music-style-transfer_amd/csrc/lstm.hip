@@ -11,7 +11,8 @@
 // is LDS-only (MST_LDS_BARRIER), so streamed stores / prefetches never stall a step.
 #include "mst_common.h"
 
-__device__ __forceinline__ float sigm(float x) { return __fdividef(1.f, 1.f + MST_FAST_EXP(-x)); }
+#define LSTM_ZS 8192        // floats of LDS holding staged per-step operands in the register flavours
+__device__ __forceinline__ float sigm(float x) { return MST_FAST_RCP(1.f + MST_FAST_EXP(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 2.f * sigm(2.f * x) - 1.f; }
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -28,6 +29,10 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
     const int H = d.H, G = 4 * d.H, tid = threadIdx.x;
     __shared__ float h_s[256];
     __shared__ float z_s[1024];
+    // REG: the input-projection rows of the next LSTM_ZS / 4H steps wait in LDS, fetched together.  (Prefetching one step
+    // ahead left every step waiting out most of an L2 / HBM round trip: 1.0-1.4 us per step for ~0.4 us of work.)
+    __shared__ float zx_s[REG ? LSTM_ZS : 1];
+    const int zchunk = REG ? LSTM_ZS / G : 1;
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* zx = b.p[SP_WS] + d.zx_off;
     float* ws = b.p[SP_WS];
@@ -46,8 +51,12 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bias[q] = b.p[SP_PAR][d.bhh_off + q * H + tid];
-            zq[q] = zx[((int64_t)bi * d.S + s0) * G + q * H + tid];
+            if (!REG) zq[q] = zx[((int64_t)bi * d.S + s0) * G + q * H + tid];
         }
+    }
+    if (REG) {               // landed before the loop: the step loop then holds no load wait that would also drain its stores
+#pragma unroll
+        for (int q = 0; q < 4; ++q) MST_PIN(bias[q]);
     }
     if (tid < 256) h_s[tid] = 0.f;
     float c = 0.f;
@@ -55,7 +64,21 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
         const int s = d.reverse ? d.S - 1 - step : step;
         const int64_t row = (int64_t)bi * d.S + s;
         float zn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (tid < H && step + 1 < d.S) {                    // next step's zx row: in flight under this step's matvec
+        if (REG) {
+            if (step % zchunk == 0) {
+                if (step) MST_LDS_BARRIER();                 // the gate lanes are done with the previous chunk
+                const int cnt = min(zchunk, d.S - step);
+                if (tid < G) {
+                    // global-address-space pointer: a generic one may alias LDS, and every load then waits for the previous
+                    // iteration's LDS store
+                    const MST_GLOBAL_AS float* zg = (const MST_GLOBAL_AS float*)zx + (int64_t)bi * d.S * G + tid;
+                    const int sstep = d.reverse ? -G : G;
+                    zg += (int64_t)(d.reverse ? d.S - 1 - step : step) * G;
+#pragma unroll 8
+                    for (int i = 0; i < cnt; ++i) zx_s[i * G + tid] = zg[(int64_t)i * sstep];      // independent loads, all in flight
+                }
+            }
+        } else if (tid < H && step + 1 < d.S) {             // next step's zx row: in flight under this step's matvec
             const int sn = d.reverse ? s - 1 : s + 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) zn[q] = zx[((int64_t)bi * d.S + sn) * G + q * H + tid];
@@ -108,6 +131,10 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
         }
         MST_LDS_BARRIER();
         if (tid < H) {
+            if (REG) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zq[q] = zx_s[(step % zchunk) * G + q * H + tid];
+            }
             const float ig = sigm(z_s[tid] + zq[0] + bias[0]), fg = sigm(z_s[H + tid] + zq[1] + bias[1]);
             const float gg = tanh_fast(z_s[2 * H + tid] + zq[2] + bias[2]), og = sigm(z_s[3 * H + tid] + zq[3] + bias[3]);
             tmp[d.hprev_off + row * H + tid] = h_s[tid];
@@ -120,8 +147,10 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
             tmp[d.c_off + row * H + tid] = c;
             ws[d.out_off + row * d.out_ld + tid] = h;
             h_s[tid] = h;
+            if (!REG) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) zq[q] = zn[q];
+                for (int q = 0; q < 4; ++q) zq[q] = zn[q];
+            }
         }
     }
 }
@@ -154,25 +183,45 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
     float dc_next = 0.f;
     // streamed operands of a step (saved gates, cell states, incoming gradient), prefetched one step ahead
     float sv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const MST_GLOBAL_AS float* tmpg = (const MST_GLOBAL_AS float*)tmp;      // not generic: cannot alias the LDS staging
+    const MST_GLOBAL_AS float* grg = (const MST_GLOBAL_AS float*)gr;
 #define LSTM_LOAD(STEP, DST)                                                                            \
     {                                                                                                   \
         const int s_ = d.reverse ? d.S - 1 - (STEP) : (STEP);                                           \
         const int sp_ = d.reverse ? s_ + 1 : s_ - 1;                                                    \
         const int64_t row_ = (int64_t)bi * d.S + s_;                                                    \
-        const float* g_ = tmp + d.gates_off + row_ * G;                                                 \
+        const MST_GLOBAL_AS float* g_ = tmpg + d.gates_off + row_ * G;                                  \
         DST[0] = g_[tid]; DST[1] = g_[H + tid]; DST[2] = g_[2 * H + tid]; DST[3] = g_[3 * H + tid];     \
-        DST[4] = tmp[d.tc_off + row_ * H + tid];                                                        \
-        DST[5] = (STEP) > 0 ? tmp[d.c_off + ((int64_t)bi * d.S + sp_) * H + tid] : 0.f;                 \
-        DST[6] = gr[d.gout_off + row_ * d.out_ld + tid];                                                \
+        DST[4] = tmpg[d.tc_off + row_ * H + tid];                                                       \
+        DST[5] = (STEP) > 0 ? tmpg[d.c_off + ((int64_t)bi * d.S + sp_) * H + tid] : 0.f;                \
+        DST[6] = grg[d.gout_off + row_ * d.out_ld + tid];                                               \
     }
-    if (tid < H) LSTM_LOAD(d.S - 1, sv)
+    // REG: the streamed operands of the next LSTM_ZS / 7H steps are fetched together and parked in LDS, each lane in slots
+    // of its own (no barrier): one step of prefetch left a step waiting out most of a memory round trip
+    __shared__ float sv_s[REG ? LSTM_ZS : 1];
+    const int schunk = REG ? LSTM_ZS / (7 * H) : 1;
+    if (!REG && tid < H) LSTM_LOAD(d.S - 1, sv)
     __syncthreads();
     for (int step = d.S - 1; step >= 0; --step) {
         const int s = d.reverse ? d.S - 1 - step : step;
         const int64_t row = (int64_t)bi * d.S + s;
         float nx[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tid < H) {
-            if (step > 0) LSTM_LOAD(step - 1, nx)
+            if (REG) {
+                const int pos = d.S - 1 - step, slot = pos % schunk;
+                if (slot == 0) {
+                    const int cnt = min(schunk, step + 1);
+#pragma unroll 4
+                    for (int i = 0; i < cnt; ++i) {          // independent loads, all in flight
+                        float t[7];
+                        LSTM_LOAD(step - i, t)
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) sv_s[(i * 7 + q) * H + tid] = t[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) sv[q] = sv_s[(slot * 7 + q) * H + tid];
+            } else if (step > 0) LSTM_LOAD(step - 1, nx)
             const float ig = sv[0], fg = sv[1], gg = sv[2], og = sv[3], tc = sv[4], cprev = sv[5];
             float dhr;
             if (chunked) {
@@ -237,7 +286,7 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
                 }
             }
         }
-        if (tid < H) {
+        if (!REG && tid < H) {
 #pragma unroll
             for (int q = 0; q < 7; ++q) sv[q] = nx[q];     // the prefetch landed under the matvec above
         }

@@ -18,6 +18,11 @@
 // libm-accurate expf/tanhf bodies sit on the critical path; the interpreter maps it to expf
 #ifndef MST_FAST_EXP
 #define MST_FAST_EXP(x) __expf(x)
+// v_rcp_f32 (1 ulp); __fdividef expands to the full IEEE division sequence (div_scale, rcp, 4 fma, div_fmas, div_fixup)
+#define MST_FAST_RCP(x) __builtin_amdgcn_rcpf(x)
+// makes a loaded value live HERE: the compiler waits for the load at this point instead of at its first use — inside a loop
+// that also stores, that wait (vmcnt counts stores too on gfx9) would drain the previous iteration's stores every iteration
+#define MST_PIN(x) asm volatile("" : "+v"(x))
 #endif
 #ifndef MST_LDS_BARRIER
 #define MST_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

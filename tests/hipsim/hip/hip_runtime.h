@@ -38,6 +38,8 @@ extern "C" void __sanitizer_finish_switch_fiber(void*, const void**, size_t*);
 #define MST_GLOBAL_AS
 #define MST_LDS_BARRIER() __syncthreads()
 #define MST_FAST_EXP(x) expf(x)
+#define MST_FAST_RCP(x) (1.f / (x))
+#define MST_PIN(x) ((void)0)
 #define MST_WAVE_SYNC() hipsim::wave_barrier()
 #define MST_SCHED_FENCE() ((void)0)
 
