@@ -847,11 +847,26 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabEntry* __res
     const int rows = e.reps * e.splits;
     const int r0 = (int)((int64_t)rows * g / 4), r1 = (int)((int64_t)rows * (g + 1) / 4);
     const int i = blk.start + lane;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent chains keep 8 loads in flight
+    // 32 loads in flight per lane (four batches of the 8 chains): entries with ~1000 rows (per-clip, per-workgroup slabs of the
+    // note kernels in a 64-clip plan) are a chain of rows / 4 / 32 memory round trips
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < e.count) {
-        const float* src = b.p[SP_TMP] + e.src + i;
+        const MST_GLOBAL_AS float* src = (const MST_GLOBAL_AS float*)(b.p[SP_TMP] + e.src + i);
         int rep = r0 / e.splits, sp = r0 - rep * e.splits;
         int r = r0;
+        for (; r + 32 <= r1; r += 32) {
+            int64_t o[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { o[q] = (int64_t)rep * e.rep_stride + (int64_t)sp * e.stride; if (++sp == e.splits) { sp = 0; ++rep; } }
+            float v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = src[o[q]];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] += v[8 * h + q];
+            }
+        }
         for (; r + 8 <= r1; r += 8) {
             int64_t o[8];
 #pragma unroll

@@ -73,9 +73,22 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(const float* pp, con
     const float* T = pitched ? pt : ut;
     for (int64_t base = (int64_t)blk * 256; base < n; base += (int64_t)nb * 256) {
         const int rows = (int)(n - base < 256 ? n - base : 256), cnt = rows * nf;
-        const float* Pg = P + base * nf;
-        const float* Tg = T + base * nf;
-        for (int j = threadIdx.x; j < cnt; j += 256) { tile_p[j] = Pg[j]; tile_t[j] = Tg[j]; }
+        // global-address-space pointers: through generic ones every load waits for the previous LDS store (may alias)
+        const MST_GLOBAL_AS float* Pg = (const MST_GLOBAL_AS float*)(P + base * nf);
+        const MST_GLOBAL_AS float* Tg = (const MST_GLOBAL_AS float*)(T + base * nf);
+        {
+            float pv[5], tv[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {           // clamped, unconditional: all ten loads in flight
+                const int j = min((int)threadIdx.x + 256 * u, cnt - 1);
+                pv[u] = Pg[j]; tv[u] = Tg[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int j = threadIdx.x + 256 * u;
+                if (j < cnt) { tile_p[j] = pv[u]; tile_t[j] = tv[u]; }
+            }
+        }
         __syncthreads();
         if ((int)threadIdx.x < rows) {
             if (pitched) note_terms<5>(tile_p + threadIdx.x * 5, tile_t + threadIdx.x * 5, acc);
@@ -278,11 +291,13 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
         gp += k * lb.grad; gu += k * lb.grad; gi += k * lb.grad; gm += k * lb.grad; gb += k * lb.grad;
     }
     if (threadIdx.x < N_TAPE_IN) {
+        // all 30 loads first (a conditional load per leaf was a chain of 15 dependent round trips at the head of every workgroup)
+        float gk[MST_N_LOSSES], sk[MST_N_LOSSES];
+#pragma unroll
+        for (int k = 0; k < MST_N_LOSSES; ++k) { gk[k] = gl[k]; sk[k] = saved[SAVED_J + k * N_TAPE_IN + threadIdx.x]; }
         float c = 0.f;
-        for (int k = 0; k < MST_N_LOSSES; ++k) {
-            const float g = gl[k];
-            if (g != 0.f) c += g * saved[SAVED_J + k * N_TAPE_IN + threadIdx.x];
-        }
+#pragma unroll
+        for (int k = 0; k < MST_N_LOSSES; ++k) c += gk[k] != 0.f ? gk[k] * sk[k] : 0.f;
         coef[threadIdx.x] = c;
     }
     __syncthreads();
@@ -302,10 +317,22 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
         // tiles of 256 positions through LDS: unit-stride loads and stores (see loss_partials_kernel)
         for (int64_t base = (int64_t)blk * 256; base < n; base += (int64_t)nb * 256) {
             const int rows = (int)(n - base < 256 ? n - base : 256), cnt = rows * nf;
-            const float* Pg = P + base * nf;
-            const float* Tg = T + base * nf;
-            float* Gg = G + base * nf;
-            for (int j = threadIdx.x; j < cnt; j += 256) { tile_p[j] = Pg[j]; tile_t[j] = Tg[j]; }
+            const MST_GLOBAL_AS float* Pg = (const MST_GLOBAL_AS float*)(P + base * nf);
+            const MST_GLOBAL_AS float* Tg = (const MST_GLOBAL_AS float*)(T + base * nf);
+            MST_GLOBAL_AS float* Gg = (MST_GLOBAL_AS float*)(G + base * nf);
+            {
+                float pv[5], tv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {       // clamped, unconditional: all ten loads in flight
+                    const int j = min((int)threadIdx.x + 256 * u, cnt - 1);
+                    pv[u] = Pg[j]; tv[u] = Tg[j];
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int j = threadIdx.x + 256 * u;
+                    if (j < cnt) { tile_p[j] = pv[u]; tile_t[j] = tv[u]; }
+                }
+            }
             __syncthreads();
             if ((int)threadIdx.x < rows) {
                 float* p = tile_p + threadIdx.x * nf;             // the gradient record replaces the prediction's
@@ -325,7 +352,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* pp, const fl
                 }
             }
             __syncthreads();
-            for (int j = threadIdx.x; j < cnt; j += 256) Gg[j] = tile_p[j];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int j = threadIdx.x + 256 * u;
+                if (j < cnt) Gg[j] = tile_p[j];
+            }
             __syncthreads();
         }
     } else {
