@@ -313,16 +313,16 @@ struct mst_plan {
     // up to 2048 rows (64 MFMA k-tiles, at 64 clips) and the slab traffic of the deferred reduction shrinks accordingly.
     // batched plans on the 64x64 tiling fold the clips into the reduction of their weight-gradient GEMMs (GemmDesc.fold_rows)
     bool folds_clips() const { return K() > 1 && (opt.gemm_tile == 64 || (opt.gemm_tile == 0 && K() >= 6)); }
-    // k-splits of a folded reduction: enough (tile, split) workgroups to fill the chip about three times over, at least
+    // k-splits of a folded reduction: enough (tile, split) workgroups to fill every workgroup slot of the chip once (256 CUs x 4), at least
     // 128 reduction rows per split; the slab a split writes is one weight gradient, so many splits of a small weight are cheap
     int fold_splits(int rows, int M, int N, int members) const {
         const int64_t kt = (int64_t)rows * K();
         const int64_t t = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * members;      // `members` like GEMMs share the launch
-        int64_t s = (768 + t - 1) / t;
+        int64_t s = (1024 + t - 1) / t;
         const int64_t kmax = kt / 128;
         if (s > kmax) s = kmax;
         while (s > 1 && (int64_t)M * N * s > (int64_t)4 << 20) --s;      // <= 16 MB of slab per weight
-        s = s < 1 ? 1 : (s > 256 ? 256 : s);
+        s = s < 1 ? 1 : (s > 512 ? 512 : s);
         const int64_t chunk = ((kt + s - 1) / s + 31) / 32 * 32;          // the kernel rounds a split's share to whole k-tiles:
         return (int)((kt + chunk - 1) / chunk);                           // no split may come out empty (its slab would stay unwritten)
     }
