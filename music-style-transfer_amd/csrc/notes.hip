@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __re
 #pragma unroll
             for (int j = 0; j < W; ++j) acc[j] = fmaf(out[j], nc, acc[j]);
         }
+        const float rS = 1.f / S;
 #pragma unroll
-        for (int j = 0; j < W; ++j) acc[j] = acc[j] / S;
+        for (int j = 0; j < W; ++j) acc[j] = acc[j] * rS;
         if (valid) st_vec<W>(ws + d.out_off + (((int64_t)q * NF + f) * NPN + n) * W, acc);
     }
 }
@@ -257,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* _
             const int c = p / d.Q, q = p - c * d.Q;
             const float nc = tmp[d.stats_off + c];
             const float ac = wave_sum64(lane < d.nwc ? tmp[d.part_off + (int64_t)c * d.nwc + lane] : 0.f);
-            const float k2 = (ac - bsum) / S;
+            // two divisions per position instead of two per element: v_div_scale / v_rcp / 4 fma / div_fmas / div_fixup sequences
+            // were a seventh of the sweep's instructions
+            const float ncS = nc / S, k2n = ((ac - bsum) / S) / nc;
             float octv[W], degv[W];
             ld_vec<W>(ws + d.oct_off + ((int64_t)p * NOCT + o) * W, octv);
             ld_vec<W>(ws + d.deg_off + ((int64_t)p * NDEG + dg) * W, degv);
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* _
                 float gm[W];
 #pragma unroll
                 for (int j = 0; j < W; ++j) {              // combine backward, then the linear's leaky
-                    const float dx = gv[j] * nc / S + k2 * (out[j] / nc);
+                    const float dx = fmaf(gv[j], ncS, k2n * out[j]);
                     gm[j] = valid ? dx * dlrelu(out[j]) : 0.f;
                 }
                 MST_WAVE_SYNC();                           // the previous sweep's fragment reads are done
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
                 float* out = ws + d.out_off + (row * NPN + n) * NPF;
 #pragma unroll
                 for (int i = 0; i < NPF; ++i) {
-                    const float s = 1.f / (1.f + expf(-z[i]));
+                    const float s = MST_FAST_RCP(1.f + MST_FAST_EXP(-z[i]));      // v_exp / v_rcp: ~2 ulp, against ~40 instructions
                     out[i] = i == 0 ? 6.f * s : s;
                 }
             }
@@ -708,7 +711,7 @@ int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
 // no float atomics.
 __device__ __forceinline__ float rl_act(int act, float z, int col) {
     if (act == ACT_LEAKY) return lrelu(z);
-    if (act == ACT_SIGOUT) { const float s = 1.f / (1.f + expf(-z)); return col == 0 ? 6.f * s : s; }
+    if (act == ACT_SIGOUT) { const float s = MST_FAST_RCP(1.f + MST_FAST_EXP(-z)); return col == 0 ? 6.f * s : s; }
     return z;
 }
 __device__ __forceinline__ float rl_dact(int act, float y, int col) {
