@@ -143,15 +143,20 @@ __global__ __launch_bounds__(256) void combine_bwd_apply_kernel(const CombineDes
     __syncthreads();
     const float S = nc_s[d.Cn];
     const float bsum = coef[d.Cn];
+    __shared__ float fa_s[COMBINE_MAXC], fb_s[COMBINE_MAXC];      // per-channel factors: dx_c = g fa_c + fb_c x_c
+    if ((int)threadIdx.x < d.Cn) {
+        const float nc = nc_s[threadIdx.x];
+        fa_s[threadIdx.x] = nc / S; fb_s[threadIdx.x] = ((coef[threadIdx.x] - bsum) / S) / nc;
+    }
+    __syncthreads();
     const int64_t n = (int64_t)d.rows * d.cols;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < (int)n; e += d.nblk * 256) {
         const int64_t eo = elem_off(d, e);
         const float g = gr[d.gout_off + e];
         for (int c = 0; c < d.Cn; ++c) {
-            const float nc = nc_s[c];
             const float x = ws[d.x_off + (int64_t)c * d.cs + eo];
             float* gx = gr + d.gx_off + (int64_t)c * d.cs + eo;
-            const float v = g * nc / S + ((coef[c] - bsum) / S) * (x / nc);
+            const float v = fmaf(g, fa_s[c], fb_s[c] * x);
             *gx = d.first ? v : *gx + v;
         }
     }
@@ -271,6 +276,14 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
     __syncthreads();
     const float S = nc_s[d.Cn];
     const float bsum = coef[d.Cn];
+    // per-channel factors once per lane (two IEEE divisions per element and channel were most of the elementwise pass):
+    // dx_c = g n_c / S + ((b_c - b) / S) x_c / n_c
+    float fa[MC], fb[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        const float nc = c < d.Cn ? nc_s[c] : 1.f;
+        fa[c] = nc / S; fb[c] = c < d.Cn ? ((coef[c] - bsum) / S) / nc : 0.f;
+    }
     for (int e0 = threadIdx.x; e0 < n; e0 += 256 * U) {
         float x[U][MC], old[U][MC], g[U];
         int64_t eo[U];
@@ -293,8 +306,7 @@ __global__ __launch_bounds__(256) void combine_small_bwd_kernel(const CombineDes
 #pragma unroll
                 for (int c = 0; c < MC; ++c) {
                     if (c < d.Cn) {
-                        const float nc = nc_s[c];
-                        const float v = g[u] * nc / S + ((coef[c] - bsum) / S) * (x[u][c] / nc);
+                        const float v = fmaf(g[u], fa[c], fb[c] * x[u][c]);
                         gr[d.gx_off + (int64_t)c * d.cs + eo[u]] = d.first ? v : old[u][c] + v;
                     }
                 }
