@@ -240,7 +240,36 @@ def surface_leg(dev, clip, iters, warm):
 
     dt_f, _ = timed(fused_body)
     dt, packed = timed(body)
-    return dict(value=iters / dt, fused_value=iters / dt_f, fused_ms_per_step=dt_f / iters * 1e3, unit='iters/s', ms_per_step=dt / iters * 1e3, steps=iters, warmup=warm,
+
+    # songs differ in (C, R): the training loop sees a new shape almost every iteration.  Six synthetic clips of different
+    # shapes in rotation through the fused body — one plan + one captured graph per shape, built during the warm-up
+    # rotations and reused afterwards (plan cache: 16 shapes)
+    from tools.synth import synth_clip
+    shapes = [(4, 16), (3, 12), (4, 24), (2, 20), (5, 8), (4, 12)]
+    songs = []
+    for i, (C_, R_) in enumerate(shapes):
+        sc = synth_clip(20 + i, C_, R_, CLIP['T'], True)
+        songs.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()})
+
+    def varying_body(it):
+        sg = songs[it % len(songs)]
+        packed = model.train_iteration(sg['mode'], sg['bpm'], sg['pitched'], sg['instruments_features'], sg['unpitched'],
+                                       sg['used_instruments'], sg['bpm_int'])
+        if (it + 1) % ITER_SIZE == 0:
+            opt.step()
+        return packed
+
+    for it in range(3 * len(songs)):
+        varying_body(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        varying_body(it)
+    torch.cuda.synchronize()
+    dt_v = time.perf_counter() - t0
+    return dict(value=iters / dt, fused_value=iters / dt_f, fused_ms_per_step=dt_f / iters * 1e3,
+                fused_varying_shapes_value=iters / dt_v, varying_shapes='(C,R) in ' + str(shapes) + ' in rotation, T=4, percussion',
+                unit='iters/s', ms_per_step=dt / iters * 1e3, steps=iters, warmup=warm,
                 config=dict(workload='the same clip through the reference\'s Python surface (style.model.StyleTransferModel.forward, '
                                      'get_total_loss, autograd backward, FusedAdam every 2nd iteration), eager, no hipGraph',
                             final_total_loss=float(packed.cpu()[0])))
