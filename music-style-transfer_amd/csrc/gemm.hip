@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
     const OutSpec& o = d.out;
     if constexpr (OK == OUT_STORE) {
         float v = acc;
-        if (bias) v += bias[n];
+        if (bias) v += o.bias_div > 0 ? bias[(unsigned)((m / o.bias_div) * o.bias_ld + n)] : bias[n];
         cbase[(unsigned)(m * o.ldc + n)] = act_fwd(o.act, v, n);
     } else if constexpr (OK == OUT_ACCUM) {
         float* c = cbase + (unsigned)(m * o.ldc + n);
@@ -736,6 +736,18 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherDesc* __restric
         rc[2] = t % (unsigned)d.d[2]; t /= (unsigned)d.d[2];
         rc[1] = t % (unsigned)d.d[1]; rc[0] = t / (unsigned)d.d[1];
         float* out = b.p[SP_WS] + d.out_off + (int64_t)row * d.K;
+        if (d.sum) {                                    // broadcast sum: out[row, w] = sum over the segments, in segment order
+            for (int w = lane; w < d.K; w += 64) {
+                float a = 0.f;
+                for (int sIdx = 0; sIdx < d.nseg; ++sIdx) {
+                    const Seg& sg = d.seg[sIdx];
+                    const int srow = rc[0] * sg.s[0] + rc[1] * sg.s[1] + rc[2] * sg.s[2] + rc[3] * sg.s[3];
+                    a += b.p[sg.space][sg.off + (int64_t)srow * sg.ld + w];
+                }
+                out[w] = a;
+            }
+            continue;
+        }
         for (int sIdx = 0; sIdx < d.nseg; ++sIdx) {
             const Seg& sg = d.seg[sIdx];
             const int srow = rc[0] * sg.s[0] + rc[1] * sg.s[1] + rc[2] * sg.s[2] + rc[3] * sg.s[3];
@@ -789,6 +801,7 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
 #pragma unroll
     for (int q = 3; q >= 0; --q) { cr[q] = t % rd[q]; t /= rd[q]; }
     const float* src = b.p[SP_GRAD] + d.src_off + d.start + w;
+    const float* ysrc = b.p[SP_WS] + d.y_off + d.start + w;          // d.act: the activation whose derivative scales src
     const int64_t s3 = d.src_ld, s2 = s3 * d.d[3], s1 = s2 * d.d[2], s0 = s1 * d.d[1];
     auto offset = [&]() { return (kc[0] + cr[0]) * s0 + (kc[1] + cr[1]) * s1 + (kc[2] + cr[2]) * s2 + (kc[3] + cr[3]) * s3; };
     auto advance = [&]() {
@@ -803,10 +816,22 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = src[o[q]];
+        if (d.act != ACT_NONE) {
+            float y[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[q] = ysrc[o[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= act_bwd(d.act, y[q], d.start + w);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += v[q];
     }
-    for (; rr < r_end; ++rr) { acc += src[offset()]; advance(); }
+    for (; rr < r_end; ++rr) {
+        const int64_t o = offset();
+        float v = src[o];
+        if (d.act != ACT_NONE) v *= act_bwd(d.act, ysrc[o], d.start + w);
+        acc += v; advance();
+    }
     if (d.nchunk == 1) { float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld + w; *dst = d.first ? acc : *dst + acc; }
     else b.p[SP_TMP][d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width + w] = acc;
 }

@@ -94,6 +94,7 @@ struct OutSpec {
     int32_t first;       // OUT_ACCUM: 1 = first writer of its (dense) target in this pass: store instead of += (no memset needed)
     int32_t wcols;       // OUT_SLAB: columns n < wcols are weights (row-major m*wcols+n); n == wcols is the bias column
     int32_t pb, pc;      // OUT_PERMW_SLAB: same column permutation as OPK_PERMW
+    int32_t bias_div, bias_ld;   // OUT_STORE with an activation bias: bias_div > 0 -> row m adds bias row m / bias_div (stride bias_ld)
 };
 struct GemmDesc {
     int32_t M, N, K, ksplit;
@@ -113,6 +114,7 @@ struct GemmDesc {
 // ---- gather: out[row, :] = concat_s seg_s[index_s(row), :]   (cat_with_broadcast, materialised once)
 struct GatherDesc {
     int32_t rows, K, nseg;
+    int32_t sum;         // 1: the segments (all K wide, start 0) are ADDED instead of concatenated (a broadcast sum)
     int32_t d[4];
     int64_t out_off;     // [SP_WS] rows x K contiguous
     Seg seg[MAX_SEG];
@@ -130,6 +132,8 @@ struct SegRedDesc {
     int64_t part_off;    // [SP_TMP] nidx * nchunk * width
     int32_t blk_begin;   // first workgroup of this member inside its clip's block range of the (merged) launch
     int32_t first;       // 1 = first writer of dst in this pass: store instead of +=
+    int32_t act;         // != ACT_NONE: the summed values are src x act'(y), y = the activation at y_off [SP_WS], laid out like src
+    int64_t y_off;
 };
 
 // ---- LSTM recurrence

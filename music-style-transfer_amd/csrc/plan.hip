@@ -274,7 +274,7 @@ struct mst_plan {
         return g;
     }
     SegRedDesc reloc(SegRedDesc r, int k) const {
-        r.src_off += shift(SP_GRAD, k); r.dst_off += shift(SP_GRAD, k); r.part_off += shift(SP_TMP, k);
+        r.src_off += shift(SP_GRAD, k); r.dst_off += shift(SP_GRAD, k); r.part_off += shift(SP_TMP, k); r.y_off += shift(SP_WS, k);
         return r;
     }
     LstmDesc reloc(LstmDesc l, int k) const {           // whht (W_hh transposed) is shared: parameters only
@@ -345,20 +345,21 @@ struct mst_plan {
 
     // cat_with_broadcast (style/utils/pytorch.py:54-65) of several sources, materialised once.
     // forward: gather kernel; backward: segment-reduce of the concat's gradient into each source.
-    T gather(int stage, const int rs[4], const std::vector<SegIn>& segs) {
+    // sum = true: the segments (equal widths) are added instead of concatenated — out = sum of the broadcast sources
+    T gather(int stage, const int rs[4], const std::vector<SegIn>& segs, bool sum = false) {
         if (segs.size() > MAX_SEG) err = MST_ERR_UNSUPPORTED;
         const int rows = rs[0] * rs[1] * rs[2] * rs[3];
         int K = 0;
-        for (auto& s : segs) K += s.width;
+        for (auto& s : segs) { if (sum) { if (K && K != s.width) err = MST_ERR_UNSUPPORTED; K = s.width; } else K += s.width; }
         T out = newT(rows, K);
-        GatherDesc g{}; g.rows = rows; g.K = K; g.nseg = (int)segs.size(); g.out_off = out.off;
+        GatherDesc g{}; g.rows = rows; g.K = K; g.nseg = (int)segs.size(); g.out_off = out.off; g.sum = sum ? 1 : 0;
         for (int q = 0; q < 4; ++q) g.d[q] = rs[q];
         int start = 0;
         for (size_t i = 0; i < segs.size(); ++i) {
             Seg& s = g.seg[i];
             s.space = segs[i].space; s.off = segs[i].off; s.ld = segs[i].ld; s.start = start; s.width = segs[i].width;
             for (int q = 0; q < 4; ++q) s.s[q] = segs[i].s[q];
-            start += segs[i].width;
+            if (!sum) start += segs[i].width;
         }
         Op op; op.stage = stage;
         op.fwd.push_back(Step{K_GATHER, (int)gathers.size(), 1, rows, 0});
@@ -390,7 +391,7 @@ struct mst_plan {
                 if (r.nidx * r.nchunk > maxidx) maxidx = r.nidx * r.nchunk;
                 segreds.push_back(r); ++cnt;
             }
-            start += s.width;
+            if (!sum) start += s.width;
         }
         if (cnt) op.bwd.push_back(Step{K_SEGRED, first, cnt, maxidx, stage2});
         ops.push_back(op);
@@ -570,8 +571,11 @@ struct mst_plan {
     // W is the full (N x Kfull) parameter; the bias is the Linear's parameter bias (bname), a one-row activation tensor
     // (bias_act: its gradient is the column sum of dY) or absent.  The concat itself is never formed: the caller adds the
     // blocks' outputs where it consumes them.  Backward: weight-gradient block through a 2-D slab entry, dx += dY . W block.
+    // act != ACT_NONE: the block carries the Linear's activation (the weight / input gradients then read dY o act'(Y));
+    // row_bias + bias_div: output row m also adds row m / bias_div of `row_bias` (the sum of the Linear's broadcast blocks);
+    // its gradient is the sum of dY o act' over each group of bias_div rows.
     void linear_part(int stage, const T& x, bool xgrad, const std::string& wname, int k0, int Kfull, const std::string& bname,
-                     const T* bias_act, int N, const T& out, int col0) {
+                     const T* bias_act, int N, const T& out, int col0, int act = ACT_NONE, const T* row_bias = nullptr, int bias_div = 0) {
         const int rows = x.rows, kb = x.cols;
         const int64_t woff = pt.off(wname) + k0;
         Op op; op.stage = stage;
@@ -579,17 +583,22 @@ struct mst_plan {
             GemmDesc g{}; g.M = rows; g.N = N; g.K = kb; g.ksplit = 1;
             g.A.kind = OPK_DENSE; g.A.space = SP_WS; g.A.off = x.off; g.A.si = x.ld; g.A.sj = 1; g.A.ones_at = -1; g.A.kfast = 1;
             g.B.kind = OPK_DENSE; g.B.space = SP_PAR; g.B.off = woff; g.B.si = 1; g.B.sj = Kfull; g.B.ones_at = -1; g.B.kfast = 1;
-            g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = ACT_NONE; g.out.off = out.off + col0;
+            g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = act; g.out.off = out.off + col0;
             g.out.bias_space = -1;
             if (!bname.empty()) { g.out.bias_space = SP_PAR; g.out.bias_off = pt.off(bname); }
             else if (bias_act) { g.out.bias_space = SP_WS; g.out.bias_off = bias_act->off + col0; }
+            else if (row_bias) { g.out.bias_space = SP_WS; g.out.bias_off = row_bias->off; g.out.bias_div = bias_div; g.out.bias_ld = row_bias->ld; }
+            if (row_bias && (rows % bias_div || row_bias->rows != rows / bias_div || row_bias->cols != N)) err = MST_ERR_UNSUPPORTED;
             op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
             gemms.push_back(g);
         }
         const bool pbias = !bname.empty();
         {   // dW block | db  =  dY^T [X | 1]
             GemmDesc w{}; w.M = N; w.N = kb + (pbias ? 1 : 0); w.K = rows; w.ksplit = splits_for(rows);
-            w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = out.off + col0; w.A.si = 1; w.A.sj = out.ld; w.A.ones_at = -1; w.A.kfast = 0;
+            if (act != ACT_NONE) {
+                w.A.kind = OPK_ACTGRAD; w.A.space = SP_GRAD; w.A.off = out.off + col0; w.A.space2 = SP_WS; w.A.off2 = out.off + col0;
+                w.A.ld = out.ld; w.A.act = act; w.A.transposed = 1; w.A.kfast = 0;
+            } else { w.A.kind = OPK_DENSE; w.A.space = SP_GRAD; w.A.off = out.off + col0; w.A.si = 1; w.A.sj = out.ld; w.A.ones_at = -1; w.A.kfast = 0; }
             w.B.kind = OPK_DENSE; w.B.space = SP_WS; w.B.off = x.off; w.B.si = x.ld; w.B.sj = 1; w.B.ones_at = pbias ? kb : -1; w.B.kfast = 0;
             const bool fd = folds_clips();
             if (fd) fold(w, rows);
@@ -604,14 +613,69 @@ struct mst_plan {
         }
         if (xgrad) {
             GemmDesc a{}; a.M = rows; a.N = kb; a.K = N; a.ksplit = 1;
-            a.A.kind = OPK_DENSE; a.A.space = SP_GRAD; a.A.off = out.off + col0; a.A.si = out.ld; a.A.sj = 1; a.A.ones_at = -1; a.A.kfast = 1;
+            if (act != ACT_NONE) {
+                a.A.kind = OPK_ACTGRAD; a.A.space = SP_GRAD; a.A.off = out.off + col0; a.A.space2 = SP_WS; a.A.off2 = out.off + col0;
+                a.A.ld = out.ld; a.A.act = act; a.A.transposed = 0; a.A.kfast = 1;
+            } else { a.A.kind = OPK_DENSE; a.A.space = SP_GRAD; a.A.off = out.off + col0; a.A.si = out.ld; a.A.sj = 1; a.A.ones_at = -1; a.A.kfast = 1; }
             a.B.kind = OPK_DENSE; a.B.space = SP_PAR; a.B.off = woff; a.B.si = Kfull; a.B.sj = 1; a.B.ones_at = -1; a.B.kfast = 0;
             a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = x.off; a.out.ldc = x.ld; a.out.bias_space = -1; a.out.act = ACT_NONE;
             op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, kb), 1});
             gemms.push_back(a);
         }
         if (bias_act) column_sum(op, out.off + col0, out.ld, rows, N, bias_act->off + col0);
+        if (row_bias) {          // g_row_bias[j] += sum of (dY o act')[j * bias_div .. + bias_div)
+            SegRedDesc r{}; r.src_off = out.off; r.src_ld = out.ld; r.start = col0; r.width = N;
+            r.dst_off = row_bias->off; r.dst_ld = row_bias->ld; r.nidx = rows / bias_div;
+            const int rs[4] = {rows / bias_div, bias_div, 1, 1};
+            for (int q = 0; q < 4; ++q) { r.d[q] = rs[q]; r.s[q] = 0; r.kd[q] = 1; }
+            r.s[0] = 1; r.kd[0] = rows / bias_div;
+            r.nchunk = (bias_div + 63) / 64;
+            int stage2 = 0;
+            if (r.nchunk > 1) { r.part_off = tmp((int64_t)r.nidx * r.nchunk * N); stage2 = (r.nidx * N + 255) / 256; }
+            r.act = act; r.y_off = out.off;
+            op.bwd.push_back(Step{K_SEGRED, (int)segreds.size(), 1, r.nidx * r.nchunk, stage2});
+            segreds.push_back(r);
+        }
         ops.push_back(op);
+    }
+
+    // nn.Linear + activation over cat_with_broadcast(segments) without the concat: the segment that varies along every
+    // row-space dim goes through one GEMM whose epilogue adds, per group of rs[3] rows, the SUM of the other segments' blocks
+    // (each a small GEMM over its own rows, added up by a broadcast-sum gather); none of the broadcast copies is ever formed.
+    //   out[r] = act( x_full[r] W_full^T + sum_i (x_i W_i^T)[index_i(r)] + b )
+    // Requires: exactly one full segment (stride pattern of a dense row index), every other segment constant along dim 3.
+    T linear_bcast(int stage, const int rs[4], const std::vector<SegIn>& segs, const std::vector<T>& xs, const std::vector<bool>& xg,
+                   const std::string& pre, int N, int act, const char* name = nullptr) {
+        const int rows = rs[0] * rs[1] * rs[2] * rs[3], mid = rs[0] * rs[1] * rs[2];
+        int Kfull = 0, full = -1;
+        for (auto& sg : segs) Kfull += sg.width;
+        for (size_t i = 0; i < segs.size(); ++i) if (xs[i].rows == rows) full = (int)i;
+        if (full < 0) { err = MST_ERR_UNSUPPORTED; return T{}; }
+        const std::string wname = pre + ".weight", bname = pre + ".bias";
+        std::vector<SegIn> parts;
+        int k0 = 0;
+        bool bias_done = false;
+        for (size_t i = 0; i < segs.size(); ++i) {
+            if ((int)i != full) {
+                if (segs[i].s[3] != 0) err = MST_ERR_UNSUPPORTED;
+                T P = newT(xs[i].rows, N);
+                const bool with_bias = !bias_done && xs[i].rows == 1;      // the parameter bias rides on a one-row block
+                linear_part(stage, xs[i], xg[i], wname, k0, Kfull, with_bias ? bname : std::string(), nullptr, N, P, 0);
+                bias_done |= with_bias;
+                SegIn ps = segs[i]; ps.space = SP_WS; ps.off = P.off; ps.ld = P.ld; ps.width = N; ps.grad = true;
+                parts.push_back(ps);
+            }
+            k0 += segs[i].width;
+        }
+        if (!bias_done) { err = MST_ERR_UNSUPPORTED; return T{}; }
+        const int rsm[4] = {rs[0], rs[1], rs[2], 1};
+        T S = gather(stage, rsm, parts, true);
+        if (S.rows != mid) err = MST_ERR_UNSUPPORTED;
+        T out = newT(rows, N, name);
+        k0 = 0;
+        for (int i = 0; i < full; ++i) k0 += segs[i].width;
+        linear_part(stage, xs[full], xg[full], wname, k0, Kfull, std::string(), nullptr, N, out, 0, act, &S, rs[3]);
+        return out;
     }
 
     // backward helper: g[dst_off .. + width) += sum over `rows` rows of g[src_off + r * src_ld .. + width)
@@ -790,10 +854,13 @@ void mst_plan::build() {
     T pre_cl = linear(E, SP_EXT0, 0, NPN * NPF, P_ * NF, NPN * NPF, false, m + ".channels_linear.weight",
                       m + ".channels_linear.bias", z.PRE_CL, ACT_LEAKY);
     const int rsCRTF[4] = {C, R, Tn, NF};
-    T prcat = gather(E, rsCRTF,
-                     {seg(pre_bl, R * Tn, Tn, 1, 0), seg(pre_br, 0, 1, 0, 0), seg(pre_cl, R * Tn * NF, Tn * NF, NF, 1),
-                      seg(pre_il, 1, 0, 0, 0), seg0(pre_ml), seg0(pre_bp)});
-    T prh_c = linear(E, prcat, true, m + ".linear", z.RH, ACT_LEAKY);
+    // Linear over cat_with_broadcast(beats, bars, channels, instruments, mode, bpm) (style/model.py rhythm encoders) with the
+    // concat decomposed away: only the per-fraction `channels` block runs at full row count
+    T prh_c = linear_bcast(E, rsCRTF,
+                           {seg(pre_bl, R * Tn, Tn, 1, 0), seg(pre_br, 0, 1, 0, 0), seg(pre_cl, R * Tn * NF, Tn * NF, NF, 1),
+                            seg(pre_il, 1, 0, 0, 0), seg0(pre_ml), seg0(pre_bp)},
+                           {pre_bl, pre_br, pre_cl, pre_il, pre_ml, pre_bp}, {true, true, true, true, true, true},
+                           m + ".linear", z.RH, ACT_LEAKY);
     T prh = newT(Q_ * NF, z.RH, "pitched_rhythm");
     combine(E, prh_c.off, Q_ * NF, z.RH, z.RH, (int64_t)Q_ * NF * z.RH, C, prh, true);
 
@@ -806,8 +873,8 @@ void mst_plan::build() {
         T ure_cl = linear(E, SP_EXT1, 0, NUN * NUF, Q_ * NF, NUN * NUF, false, m + ".channels_linear.weight",
                           m + ".channels_linear.bias", z.URE_CL, ACT_LEAKY);
         const int rs1RTF[4] = {1, R, Tn, NF};
-        T urcat = gather(E, rs1RTF, {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp)});
-        T urh_c = linear(E, urcat, true, m + ".linear", z.RH, ACT_LEAKY);
+        T urh_c = linear_bcast(E, rs1RTF, {seg(ure_bl, 0, Tn, 1, 0), seg(ure_br, 0, 1, 0, 0), seg(ure_cl, 0, Tn * NF, NF, 1), seg0(ure_bp)},
+                               {ure_bl, ure_br, ure_cl, ure_bp}, {true, true, true, true}, m + ".linear", z.RH, ACT_LEAKY);
         T urh = newT(Q_ * NF, z.RH, "unpitched_rhythm");
         combine(E, urh_c.off, Q_ * NF, z.RH, z.RH, 0, 1, urh, true);
         // combine(pitched, unpitched) stacks the pair on a new leading axis (style/model.py:766-767)
@@ -1017,7 +1084,8 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             operand_acc(v, g.A, g.M, gk, -1);
             operand_acc(v, g.B, gk, g.N, g.B.ones_at);
             const OutSpec& o = g.out;
-            if (o.bias_space >= 0) acc_add(v, o.bias_space, o.bias_off, g.N, false);       // a bias row that is an activation (linear_part)
+            if (o.bias_space >= 0)       // a bias row that is an activation (linear_part); bias_div: one row per bias_div output rows
+                acc_add(v, o.bias_space, o.bias_off, o.bias_div > 0 ? (int64_t)((g.M - 1) / o.bias_div) * o.bias_ld + g.N : g.N, false);
             if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
             else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true, true, g.N == o.ldc || g.M == 1);
             else if (o.kind == OUT_CONV) acc_add(v, o.space, o.off, (int64_t)(g.M / NOCT) * o.ldc, true);
@@ -1039,6 +1107,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             const SegRedDesc& r = segreds[s.first + i];
             const int64_t rows = (int64_t)r.d[0] * r.d[1] * r.d[2] * r.d[3];
             acc_add(v, SP_GRAD, r.src_off, rows * r.src_ld, false);
+            if (r.act != ACT_NONE) acc_add(v, SP_WS, r.y_off, rows * r.src_ld, false);
             acc_add(v, SP_GRAD, r.dst_off, (int64_t)(r.nidx - 1) * r.dst_ld + r.width, true, true, r.width == r.dst_ld || r.nidx == 1);
             if (r.nchunk > 1) acc_add(v, SP_TMP, r.part_off, (int64_t)r.nidx * r.nchunk * r.width, true);
             break;
