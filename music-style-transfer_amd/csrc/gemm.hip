@@ -408,7 +408,7 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     const int brow0 = BKF ? (tid >> 3) : 4 * (tid & 15), bkl0 = BKF ? 4 * (tid & 7) : (tid >> 4);
     // per-tile constants of this lane's groups: element offset of the first element at k = 0, and whether the group's rows
     // are all inside the matrix (KF = 0) / its row is (KF = 1)
-    struct Geo { int tm, tn, aoff[2], boff[2]; bool avec[2], bvec[2]; };
+    struct Geo { int tm, tn, aoff[2], boff[2]; bool avec[2], bvec[2]; bool clean; };
     auto geo_of = [&](const int t, Geo& q) {
         q.tm = t / tiles_n; q.tn = t - q.tm * tiles_n;
 #pragma unroll
@@ -420,6 +420,12 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
             q.bvec[g] = BKF ? nr < N : (nr + 3 < N) & !((b_ones >= nr) & (b_ones <= nr + 3));
             q.boff[g] = min(nr, N - 1) * sBn + (BKF ? bkl0 : 0);
         }
+        // clean tile (workgroup-uniform): every group of every lane is either wholly inside the matrix or wholly outside it
+        // and none holds the bias-ones column — a full k-tile then needs no per-element predicates at all
+        const bool a_clean = AKF || (M % 4 == 0) || ((q.tm + 1) * MF_BM <= M);
+        const bool ones_in = (b_ones >= q.tn * MF_BN) & (b_ones < (q.tn + 1) * MF_BN);
+        const bool b_clean = (BKF || (N % 4 == 0) || ((q.tn + 1) * MF_BN <= N)) & !ones_in;
+        q.clean = a_clean & b_clean;
     };
     mf_f32x16 acc;
 #pragma unroll
@@ -445,6 +451,34 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     auto issue = [&](const Geo& q, const int kt) {
         int fclip[2] = {0, 0}, fkr[2] = {0, 0};
         if ((!AKF || !BKF) && fr) fold_at(kt, fclip, fkr);
+        if (q.clean & (kt + MF_KD <= k1)) {
+            // fast path: a full k-tile of a clean tile.  One 16-byte load per group (two with the activation), the address is a
+            // lane constant plus a per-k-tile term; a group outside the matrix (lane-invariant) holds zeros.  This is the
+            // path of nearly every k-tile of the large GEMMs; the general code below cost ~300 VALU instructions per wave.
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                {
+                    const int kr = AKF ? 0 : (fr ? fkr[g] : kt + akl0 + 16 * g);
+                    const unsigned o = (unsigned)(q.aoff[g] + (AKF ? kt : kr * sAk)) + ((!AKF && fr) ? (unsigned)fclip[g] * acs : 0u);
+                    const unsigned oy = (unsigned)(q.aoff[g] + (AKF ? kt : kr * sAk)) + ((!AKF && fr) ? (unsigned)fclip[g] * acs2 : 0u);
+                    mf_f4u t = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+                    if (q.avec[g]) {
+                        t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + o);
+                        if constexpr (AK == OPK_ACTGRAD) u = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseY + oy);
+                    }
+                    va[4 * g] = t[0]; va[4 * g + 1] = t[1]; va[4 * g + 2] = t[2]; va[4 * g + 3] = t[3];
+                    if constexpr (AK == OPK_ACTGRAD) { vy[4 * g] = u[0]; vy[4 * g + 1] = u[1]; vy[4 * g + 2] = u[2]; vy[4 * g + 3] = u[3]; }
+                }
+                {
+                    const int kr = BKF ? 0 : (fr ? fkr[g] : kt + bkl0 + 16 * g);
+                    const unsigned o = (unsigned)(q.boff[g] + (BKF ? kt : kr * sBk)) + ((!BKF && fr) ? (unsigned)fclip[g] * bcs : 0u);
+                    mf_f4u t = {0.f, 0.f, 0.f, 0.f};
+                    if (q.bvec[g]) t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + o);
+                    vb[4 * g] = t[0]; vb[4 * g + 1] = t[1]; vb[4 * g + 2] = t[2]; vb[4 * g + 3] = t[3];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             // ---- A

@@ -318,7 +318,7 @@ struct mst_plan {
     int fold_splits(int rows, int M, int N, int members) const {
         const int64_t kt = (int64_t)rows * K();
         const int64_t t = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * members;      // `members` like GEMMs share the launch
-        int64_t s = (1024 + t - 1) / t;
+        int64_t s = 1024 / t;                // rounded DOWN: 1025 workgroups are two rounds of the chip
         const int64_t kmax = kt / 128;
         if (s > kmax) s = kmax;
         while (s > 1 && (int64_t)M * N * s > (int64_t)4 << 20) --s;      // <= 16 MB of slab per weight
