@@ -650,18 +650,14 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
     }
 }
 
-__global__ __launch_bounds__(MF_THREADS, 4) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
+__global__ __launch_bounds__(MF_THREADS, 4) void gemm_mfma_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ owner, int count, int blocks_per_clip, Bases b) {
     __shared__ float smem[2 * 2 * MF_KD * (MF_BM + GEMM_PAD)];        // two (A | B) tile pairs: the lean body double-buffers
     float (*As)[MF_BM + GEMM_PAD] = reinterpret_cast<float (*)[MF_BM + GEMM_PAD]>(smem);
     float (*Bs)[MF_BN + GEMM_PAD] = reinterpret_cast<float (*)[MF_BN + GEMM_PAD]>(smem + MF_KD * (MF_BM + GEMM_PAD));
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
-    // member y owns the workgroups [starts[y], starts[y + 1]) of a clip's range: binary search (a merged launch of the
-    // backward pass has hundreds of members; the linear probe was a chain of that many dependent scalar loads)
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (lb >= starts[mid]) lo = mid; else hi = mid - 1;
-    }
+    // member of this block: one uniform load from the plan's block -> member table (a binary search over the members' first
+    // blocks was log2(members) dependent scalar round trips; the linear probe before it, hundreds)
+    const int lo = owner[lb];
     const GemmDesc d = descs[clip * count + lo];
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + MF_BM - 1) / MF_BM) * ((d.N + MF_BN - 1) / MF_BN);
@@ -697,7 +693,7 @@ int gemm_blocks(const GemmDesc& g, int mfma) {
 // (workgroup-uniform) variant picks the instantiation.  That lets the scheduler put *independent*
 // GEMMs of different kinds — e.g. the weight-gradient and input-gradient GEMMs of one layer, or
 // all small Linears of one dependency level — into a single launch.
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ starts, int count, int blocks_per_clip, Bases b) {
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __restrict__ descs, const int* __restrict__ owner, int count, int blocks_per_clip, Bases b) {
     // A tile | B tile; the final reduce overlays the whole block with one 32x32 partial tile per wave
     constexpr int TILE_F = GEMM_BK * (GEMM_BM + GEMM_PAD), RED_F = (GEMM_THREADS / 64) * GEMM_BM * GEMM_BN;
     __shared__ float smem[(2 * TILE_F > RED_F) ? 2 * TILE_F : RED_F];
@@ -705,11 +701,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDesc* __re
     float (*Bs)[GEMM_BN + GEMM_PAD] = reinterpret_cast<float (*)[GEMM_BN + GEMM_PAD]>(smem + TILE_F);
     // flat 1-D grid: clip-major; inside a clip's block range member y owns [blk_begin, blk_begin + tiles * ksplit)
     const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
-    int lo = 0, hi = count - 1;                      // member y owns [starts[y], starts[y + 1]): binary search
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (lb >= starts[mid]) lo = mid; else hi = mid - 1;
-    }
+    const int lo = owner[lb];                        // member of this block: one uniform load (the plan's block -> member table)
     const GemmDesc d = descs[clip * count + lo];     // by value (scalar loads once): a reference would be re-read after every barrier
     const int local = lb - d.blk_begin;
     const int ntile = ((d.M + GEMM_BM - 1) / GEMM_BM) * ((d.N + GEMM_BN - 1) / GEMM_BN);
@@ -747,10 +739,10 @@ int gemm_variant(const GemmDesc& g) {
     return -1;
 }
 
-int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s) {
+int launch_gemm(const GemmDesc* dev_descs, const int* dev_owner, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s) {
     if (members <= 0 || blocks_per_clip <= 0 || clips <= 0) return 0;
-    if (mfma) hipLaunchKernelGGL(gemm_mfma_kernel, dim3(blocks_per_clip * clips), dim3(MF_THREADS), 0, s, dev_descs, dev_starts, members, blocks_per_clip, b);
-    else hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, dev_starts, members, blocks_per_clip, b);
+    if (mfma) hipLaunchKernelGGL(gemm_mfma_kernel, dim3(blocks_per_clip * clips), dim3(MF_THREADS), 0, s, dev_descs, dev_owner, members, blocks_per_clip, b);
+    else hipLaunchKernelGGL(gemm_kernel, dim3(blocks_per_clip * clips), dim3(GEMM_THREADS), 0, s, dev_descs, dev_owner, members, blocks_per_clip, b);
     return (int)hipGetLastError();
 }
 

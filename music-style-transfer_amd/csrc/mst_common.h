@@ -248,8 +248,8 @@ int gemm_variant(const GemmDesc& g);
 // descs = clips x members (clip-major); every clip's copy of a member has the same blk_begin inside the clip's block range
 // mfma = 1: the 64x64-tile f32-MFMA kernel (throughput), 0: the 32x32 split-K kernel (latency); blk_begin must have been
 // computed with the matching tile edge (gemm_tile_edge)
-// dev_starts: the members' blk_begin values as a dense int array (index = position of the clip-0 descriptor)
-int launch_gemm(const GemmDesc* dev_descs, const int* dev_starts, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
+// dev_owner: member index of every workgroup of one clip's block range (the plan's block -> member table of the launch)
+int launch_gemm(const GemmDesc* dev_descs, const int* dev_owner, int members, int blocks_per_clip, int clips, int mfma, Bases b, hipStream_t s);
 int gemm_tile_edge(int mfma);
 int gemm_blocks(const GemmDesc& g, int mfma);       // workgroups of one member (tiles / run x k-splits)
 int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip, int clips, int stage2_blocks, Bases b, hipStream_t s);

@@ -198,7 +198,7 @@ enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_
        // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
        K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG,
        K_GEMM_FOLD };      // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
-struct Step { int kind, first, count, a, b, stage; };
+struct Step { int kind, first, count, a, b, stage; int c = 0; };      // c: GEMM steps — offset of the step's block -> member table
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
@@ -216,7 +216,9 @@ struct mst_plan {
     std::vector<GemmDesc> s_gemms; std::vector<GatherDesc> s_gathers; std::vector<SegRedDesc> s_segreds; std::vector<LstmDesc> s_lstms;
     std::vector<CombineDesc> s_combines; std::vector<NotesDesc> s_notes; std::vector<RowLinDesc> s_rowlins;
     RowLinDesc* d_rowlins = nullptr;
-    std::vector<int> s_gemm_starts; int* d_gemm_starts = nullptr;      // blk_begin of every scheduled GEMM descriptor, densely
+    // member of every workgroup of a clip's block range, per scheduled GEMM launch (Step.c): one uniform load instead of a binary
+    // search over the members' first blocks — log2(members) dependent scalar round trips at the head of every workgroup
+    std::vector<int> s_gemm_owner; int* d_gemm_owner = nullptr;
     std::map<std::string, T> named;
     int64_t act_top = 0, tmp_top = 0;
     int64_t stage_begin[3] = {0, 0, 0}, stage_end[3] = {0, 0, 0};
@@ -1353,6 +1355,11 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                     total += gemm_blocks(g0, mfma);
                 }
                 m.a = total; m.b = nm;        // blocks per clip, members per clip
+                m.c = (int)s_gemm_owner.size();
+                for (int q = 0; q < nm; ++q) {
+                    const int nb = gemm_blocks(s_gemms[m.first + q], mfma);
+                    for (int i = 0; i < nb; ++i) s_gemm_owner.push_back(q);
+                }
             }
             if (m.kind == K_SEGRED) {    // same flat layout; m.b keeps the stage-2 block count, members = count / clips
                 const int nm = (int)members.size();
@@ -1502,9 +1509,7 @@ int mst_plan::upload() {
     int e = 0;
     e |= up(s_gemms, &d_gemms); e |= up(s_gathers, &d_gathers); e |= up(s_segreds, &d_segreds); e |= up(s_lstms, &d_lstms);
     e |= up(s_combines, &d_combines); e |= up(s_notes, &d_notes); e |= up(s_rowlins, &d_rowlins);
-    s_gemm_starts.resize(s_gemms.size());
-    for (size_t i = 0; i < s_gemms.size(); ++i) s_gemm_starts[i] = s_gemms[i].blk_begin;
-    e |= up(s_gemm_starts, &d_gemm_starts);
+    e |= up(s_gemm_owner, &d_gemm_owner);
     e |= up(copies, &d_copies); e |= up(folds, &d_folds); e |= up(zero_fwd, &d_zero_fwd);
     for (int st = 0; st < 3; ++st) e |= up(zero_stage[st], &d_zero_stage[st]);
     e |= up(zero_all, &d_zero_all);
@@ -1551,7 +1556,7 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
 
 extern "C" void mst_plan_destroy(mst_plan* p) {
     if (!p) return;
-    hipFree(p->d_gemm_starts); hipFree(p->d_rowlins); hipFree(p->d_zero_all); hipFree(p->d_copies); hipFree(p->d_folds); hipFree(p->d_zero_fwd);
+    hipFree(p->d_gemm_owner); hipFree(p->d_rowlins); hipFree(p->d_zero_all); hipFree(p->d_copies); hipFree(p->d_folds); hipFree(p->d_zero_fwd);
     for (int st = 0; st < 3; ++st) hipFree(p->d_zero_stage[st]);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
@@ -1600,7 +1605,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
 
 static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_t st) {
     switch (s.kind) {
-    case K_GEMM: case K_GEMM_FOLD: return launch_gemm(p->d_gemms + s.first, p->d_gemm_starts + s.first, s.b, s.a, s.count / s.b, p->mfma, b, st);
+    case K_GEMM: case K_GEMM_FOLD: return launch_gemm(p->d_gemms + s.first, p->d_gemm_owner + s.c, s.b, s.a, s.count / s.b, p->mfma, b, st);
     case K_GATHER: return launch_gather(p->d_gathers + s.first, s.count, s.a, b, st);
     case K_SEGRED: return launch_segred(p->d_segreds + s.first, s.count / p->K(), s.a, p->K(), s.b, b, st);
     case K_LSTM_T: return launch_lstm_transpose(p->d_lstms + s.first, s.count, s.b, p->s_lstms[s.first].multi, b, st);
