@@ -1,0 +1,45 @@
+"""Structure of the static plans, read through the C ABI's instrumentation entry points (mst_plan_step_count,
+mst_plan_step_gemms) on the CPU interpreter build: what the scheduler is documented to do is visible in
+the launch lists, so a regression that silently falls back to the unfused shapes fails here and not only in a profile."""
+import parity_cases as pc
+from simutil import sim_native
+from style import _native as nat
+
+
+def gemm_members(plan, backward):
+    out = []
+    n = plan.lib.mst_plan_step_count(plan.handle, 7, int(backward))
+    for st in range(n):
+        out.extend(plan.step_gemms(7, backward, st))
+    return out
+
+
+def test_batched_plan_folds_the_clips_into_its_weight_gradient_gemms():
+    native = sim_native()
+    dims = pc.make_dims(pc.FULL, 2, 3, 2, True)
+    dims.clips = 4
+    plan = nat.Plan(native, dims, 'cpu', gemm_tile=64)
+    assert plan.gemm_tile == 64
+    bwd = gemm_members(plan, True)
+    folded = [m for m in bwd if m[4] > 0]
+    assert folded, 'no folded weight-gradient GEMM in a 4-clip plan on the 64x64 tiling'
+    for M, N, K, splits, fold_rows, wgs in folded:
+        assert K == fold_rows * 4                    # reduction index = (clip, row)
+        assert 1 <= splits <= 512 and wgs >= splits  # at least one workgroup per k-split
+    # the one-clip plan of the same shape folds nothing
+    dims1 = pc.make_dims(pc.FULL, 2, 3, 2, True)
+    one = nat.Plan(native, dims1, 'cpu')
+    assert all(m[4] == 0 for m in gemm_members(one, True))
+
+
+def test_rhythm_encoder_linear_never_sees_the_135_wide_concat():
+    # pitched rhythm encoder (full widths): cat_with_broadcast of six segments, 135 columns in all, feeding a Linear to 32.
+    # Decomposed (linear_bcast), the only full-row GEMM of that Linear has K = 16 (the per-fraction channels block);
+    # the materialised version had a (rows x 32 x 135) forward GEMM
+    native = sim_native()
+    C, R, T = 2, 3, 2
+    plan = nat.Plan(native, pc.make_dims(pc.FULL, C, R, T, True), 'cpu')
+    fwd = gemm_members(plan, False)
+    rows = C * R * T * 10
+    assert not [m for m in fwd if m[2] == 135], 'a forward GEMM reduces over the 135-wide concat'
+    assert [m for m in fwd if m[0] == rows and m[1] == 32 and m[2] == 16], 'the channels block GEMM (rows x 32 x 16) is missing'
