@@ -512,7 +512,9 @@ struct mst_plan {
             l.gout_off = sp.out.off + sp.coloff; l.gzx_off = zxs[i].off;
             l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
 #ifndef HIPSIM      // the interpreter runs workgroups one after another: a kernel whose workgroups wait for each other cannot run there
-            l.multi = (K() == 1 && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
+            // the LSTM_NB workgroups of a sequence wait for each other, so every workgroup of the launch must be resident at once:
+            // one group per clip, at most 768 workgroups (256 CUs x 3; the kernels fit 4 per CU) — i.e. up to 64 clips per launch
+            l.multi = (LSTM_NB * K() <= 768 && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
 #endif
             l.xch_off = l.multi ? tmp(2 * (2 * H + 2 * 4 * H)) : 0;
             lstms.push_back(l);
@@ -1318,7 +1320,9 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             }
             // clip-major replication: clip k's copy of every member, relocated to clip k's workspace slices.
             // The W_hh transpose reads parameters only, so it runs once for all clips.
-            const int copies = (s0.kind == K_LSTM_T || s0.kind == K_GEMM_FOLD) ? 1 : K();
+            // (the multi-workgroup flavour's K_LSTM_T step clears per-clip exchange tags instead: one copy per clip)
+            const bool shared_T = s0.kind == K_LSTM_T && !lstms[s0.first].multi;
+            const int copies = (shared_T || s0.kind == K_GEMM_FOLD) ? 1 : K();
             for (int k = 0; k < copies; ++k) {
                 for (int idx : members) {
                     if (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD) {
