@@ -225,7 +225,9 @@ __device__ __forceinline__ void gemm_body(const GemmDesc& d, const Bases& b, con
 typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
 typedef float mf_f4u __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load that only needs 4-byte alignment
 
-template <int AK, int BKIND, int OK, int AKF, int BKF>
+// FOLD: the reduction index runs over (clip, row) (GemmDesc.fold_rows >= MF_KD rows per clip): a k-tile then crosses at most one
+// clip boundary, found with one uniform division per k-tile
+template <int AK, int BKIND, int OK, int AKF, int BKF, bool FOLD = false>
 __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b, const int tile, const int split,
                                                float (*As)[MF_BM + GEMM_PAD], float (*Bs)[MF_BN + GEMM_PAD]) {
     const int tid = threadIdx.x;
@@ -245,6 +247,8 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
     const int a_tr = d.A.transposed;
     const int b_ones = (BKIND == OPK_DENSE || BKIND == OPK_IM2COL) ? d.B.ones_at : -1;
     const bool live = (tm * MF_BM + wm * 32 < M) & (tn * MF_BN + wn * 32 < N);    // wave-uniform
+    const int fr = FOLD ? d.fold_rows : 1;
+    const unsigned acs = (unsigned)d.acs, acs2 = (unsigned)d.acs2, bcs = (unsigned)d.bcs;
     mf_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -269,26 +273,33 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
     constexpr bool VEC_B = BKIND == OPK_DENSE;
 #define MF_ISSUE(KT)                                                                                       \
     {                                                                                                      \
+        const int fc0 = FOLD ? (KT) / fr : 0, fkb = FOLD ? (fc0 + 1) * fr : 0;                              \
         _Pragma("unroll") for (int g = 0; g < NL / 4; ++g) {                                               \
             int ia[4], ib[4];                                                                              \
+            unsigned ca[4], ca2[4], cb[4];                                                                 \
             bool oka[4], okb[4], one[4];                                                                   \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
                 const int i = 4 * g + j;                                                                   \
                 const int m = tm * MF_BM + A_ROW(i), ka = (KT) + A_KL(i);                                  \
                 oka[j] = (m < M) & (ka < k1);                                                              \
-                ia[j] = off_of<AK>(d.A, m, ka, oka[j]);                                                    \
+                const int cla = FOLD ? (ka >= fkb ? fc0 + 1 : fc0) : 0;                                    \
+                ia[j] = off_of<AK>(d.A, m, FOLD ? ka - cla * fr : ka, oka[j]);                             \
                 ia[j] = oka[j] ? ia[j] : 0;                                                                \
+                ca[j] = (FOLD && oka[j]) ? (unsigned)cla * acs : 0u;                                        \
+                ca2[j] = (FOLD && oka[j]) ? (unsigned)cla * acs2 : 0u;                                      \
                 if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) {                                   \
                     /* derivative column index; the value itself is applied below */                      \
                 }                                                                                          \
                 const int n = tn * MF_BN + B_ROW(i), kb = (KT) + B_KL(i);                                  \
                 okb[j] = (n < N) & (kb < k1);                                                              \
                 one[j] = okb[j] & (n == b_ones);                                                           \
-                ib[j] = off_of<BKIND>(d.B, kb, n, okb[j]);                                                 \
+                const int clb = FOLD ? (kb >= fkb ? fc0 + 1 : fc0) : 0;                                    \
+                ib[j] = off_of<BKIND>(d.B, FOLD ? kb - clb * fr : kb, n, okb[j]);                          \
                 ib[j] = (okb[j] & !one[j]) ? ib[j] : 0;                                                    \
+                cb[j] = (FOLD && okb[j] && !one[j]) ? (unsigned)clb * bcs : 0u;                             \
             }                                                                                              \
             float xa[4], y4[4], xb[4];                                                                     \
-            const bool veca = VEC_A && oka[0] && oka[3] && (ia[3] - ia[0] == 3);                           \
+            const bool veca = !FOLD && VEC_A && oka[0] && oka[3] && (ia[3] - ia[0] == 3);                  \
             if (veca) {                                                                                    \
                 const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseA + (unsigned)ia[0]);  \
                 xa[0] = t[0]; xa[1] = t[1]; xa[2] = t[2]; xa[3] = t[3];                            \
@@ -298,16 +309,16 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmDesc& d, const Bases& b
                 }                                                                                          \
             } else {                                                                                       \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
-                    xa[j] = baseA[(unsigned)ia[j]];                                                        \
-                    if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) y4[j] = baseA2[(unsigned)ia[j]]; \
+                    xa[j] = baseA[(unsigned)ia[j] + ca[j]];                                                \
+                    if constexpr (AK == OPK_ACTGRAD || AK == OPK_CONVGRAD) y4[j] = baseA2[(unsigned)ia[j] + ca2[j]]; \
                 }                                                                                          \
             }                                                                                              \
-            const bool vecb = VEC_B && okb[0] && okb[3] && (ib[3] - ib[0] == 3) && !(one[0] | one[1] | one[2] | one[3]); \
+            const bool vecb = !FOLD && VEC_B && okb[0] && okb[3] && (ib[3] - ib[0] == 3) && !(one[0] | one[1] | one[2] | one[3]); \
             if (vecb) {                                                                                    \
                 const mf_f4u t = *reinterpret_cast<const MST_GLOBAL_AS mf_f4u*>(baseB + (unsigned)ib[0]);  \
                 xb[0] = t[0]; xb[1] = t[1]; xb[2] = t[2]; xb[3] = t[3];                            \
             } else {                                                                                       \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) xb[j] = baseB[(unsigned)ib[j]];              \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) xb[j] = baseB[(unsigned)ib[j] + cb[j]];      \
             }                                                                                              \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
                 const int i = 4 * g + j;                                                                   \
@@ -675,7 +686,10 @@ __global__ __launch_bounds__(MF_THREADS, 4) void gemm_mfma_kernel(const GemmDesc
             if (tile > t_begin) __syncthreads();
             if (d.variant == GV_LIN_FWD_PERM) gemm_mfma_body<OPK_DENSE, OPK_PERMW, OUT_STORE, 1, 1>(d, b, tile, split, As, Bs);
             else if (d.variant == GV_CONV_FWD) gemm_mfma_body<OPK_IM2COL, OPK_PERMW, OUT_CONV, 1, 1>(d, b, tile, split, As, Bs);
-            else if (d.variant == GV_CONV_DW) gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs);
+            else if (d.variant == GV_CONV_DW) {
+                if (d.fold_rows) gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0, true>(d, b, tile, split, As, Bs);
+                else gemm_mfma_body<OPK_CONVGRAD, OPK_IM2COL, OUT_PERMW_SLAB, 1, 0>(d, b, tile, split, As, Bs);
+            }
         }
         break;
     }

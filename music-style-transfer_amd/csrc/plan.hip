@@ -473,14 +473,18 @@ struct mst_plan {
         w.A.kind = OPK_CONVGRAD; w.A.space = SP_GRAD; w.A.off = x1.off; w.A.space2 = SP_WS; w.A.off2 = x1.off;
         w.A.oc = z.OC; w.A.kfast = 1;
         w.B.kind = OPK_IM2COL; w.B.space = SP_EXT0; w.B.off = 0; w.B.ones_at = K; w.B.kfast = 0;
+        const bool fd = folds_clips() && P_ * NOCT >= 64;      // the conv body's folded loader wants >= one k-tile of rows per clip
+        if (fd) fold(w, P_ * NOCT);
         const int64_t stride = (int64_t)z.OC * K + z.OC;
         const int64_t slab = tmp(stride * w.ksplit);
         w.out.kind = OUT_PERMW_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = K;
         w.out.pb = CONV_K; w.out.pc = NPF; w.out.bias_space = -1;
-        op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
+        op.bwd.push_back(Step{fd ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
         gemms.push_back(w);
-        slabs[stage_idx(stage)].push_back(SlabEntry{woff, slab, stride, z.OC * K, w.ksplit});
-        slabs[stage_idx(stage)].push_back(SlabEntry{boff, slab + (int64_t)z.OC * K, stride, z.OC, w.ksplit});
+        SlabEntry e1{woff, slab, stride, z.OC * K, w.ksplit}, e2{boff, slab + (int64_t)z.OC * K, stride, z.OC, w.ksplit};
+        e1.single = e2.single = fd ? 1 : 0;
+        slabs[stage_idx(stage)].push_back(e1);
+        slabs[stage_idx(stage)].push_back(e2);
         ops.push_back(op);
         return x1;
     }
@@ -1328,7 +1332,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                     if (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD) {
                         GemmDesc g = reloc(gemms[idx], k); g.variant = gemm_variant(g);
                         if (g.fold_rows) {          // arena sizes are final now: clip strides of the folded reduction
-                            g.acs = shift(g.A.space, 1); g.acs2 = g.A.kind == OPK_ACTGRAD ? shift(g.A.space2, 1) : 0; g.bcs = shift(g.B.space, 1);
+                            g.acs = shift(g.A.space, 1); g.acs2 = (g.A.kind == OPK_ACTGRAD || g.A.kind == OPK_CONVGRAD) ? shift(g.A.space2, 1) : 0; g.bcs = shift(g.B.space, 1);
                             // the loader adds clip * stride as a 32-bit element offset
                             if ((uint64_t)std::max(g.acs, std::max(g.acs2, g.bcs)) * (uint64_t)K() > 0xFFFFFFFFull) err = MST_ERR_UNSUPPORTED;
                         }

@@ -48,6 +48,9 @@ def test_batched_clips_on_the_mfma_gemm():
     # default (32x32 tiles with 4 clips per launch) as well
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4, gemm_tile=64)
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4)
+    # 9 positions x 8 octaves = 72 conv rows per clip: the conv weight gradient folds the clips too, and its 32-row k-tiles
+    # cross clip boundaries (72 is not a multiple of 32)
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 3, 3, 1, True, 3, gemm_tile=64)
 
 
 def test_mfma_gemm_runs_of_several_tiles_per_workgroup():
