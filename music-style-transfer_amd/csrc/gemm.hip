@@ -65,6 +65,20 @@ __device__ __forceinline__ int off_of(const Operand& o, int i, int j, bool& ok) 
     } else if constexpr (KIND == OPK_PERMW) {        // i = (a, b, c) in activation memory order, j = out feature
         // conv: (fraction, tap, feature) reads W[oc, fraction*5+feature, tap]  (pb=14, pc=5)
         // unpitched linear: (fraction, note, feature) reads W[j, fraction*94 + feature*47 + note]
+        // the two permutations the model has, with compile-time divisors (a runtime divisor is a ~25-instruction sequence,
+        // twice per element and k-tile: most of what the conv GEMM's waves issued)
+        if (o.pb == CONV_K && o.pc == NPF) {
+            constexpr int BC = CONV_K * NPF;
+            const int a = i / BC, rem = i - a * BC;
+            const int bb = rem / NPF, c = rem - bb * NPF;
+            return j * o.ld + a * BC + c * CONV_K + bb;
+        }
+        if (o.pb == NUN && o.pc == NUF) {
+            constexpr int BC = NUN * NUF;
+            const int a = i / BC, rem = i - a * BC;
+            const int bb = rem / NUF, c = rem - bb * NUF;
+            return j * o.ld + a * BC + c * NUN + bb;
+        }
         const int bc = o.pb * o.pc;
         const int a = i / bc, rem = i - a * bc;
         const int bb = rem / o.pc, c = rem - bb * o.pc;
@@ -92,9 +106,10 @@ __device__ __forceinline__ void store_out(const GemmDesc& d, float* cbase, const
     } else {                                         // OUT_PERMW_SLAB: m = out feature, n = (a, b, c) | bias column
         unsigned idx;
         if (n < o.wcols) {
-            const int bc = o.pb * o.pc;
-            const int a = n / bc, rem = n - a * bc;
-            const int bb = rem / o.pc, c = rem - bb * o.pc;
+            int a, bb, c, bc;
+            if (o.pb == CONV_K && o.pc == NPF) { bc = CONV_K * NPF; a = n / (CONV_K * NPF); const int rem = n - a * (CONV_K * NPF); bb = rem / NPF; c = rem - bb * NPF; }
+            else if (o.pb == NUN && o.pc == NUF) { bc = NUN * NUF; a = n / (NUN * NUF); const int rem = n - a * (NUN * NUF); bb = rem / NUF; c = rem - bb * NUF; }
+            else { bc = o.pb * o.pc; a = n / bc; const int rem = n - a * bc; bb = rem / o.pc; c = rem - bb * o.pc; }
             idx = (unsigned)(m * o.wcols + a * bc + c * o.pb + bb);
         } else {
             idx = (unsigned)(d.M * o.wcols + m);
