@@ -22,7 +22,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py $O/pm1_FETCH_SIZE $O/pm1_WRITE_SIZE $O/${TAG}_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-graph --no-roofline --batched-clips 0 --surface-steps 0 (two separate passes)" 1
 python tools/pmc_traffic.py $O/pm64_FETCH_SIZE $O/pm64_WRITE_SIZE $O/${TAG}_pmc_hbm_traffic_64_clips.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --clips-per-gpu 64 --steps 128 --warmup 64 --no-cpu-baseline --no-roofline (two separate passes; per_iteration = per clip-iteration)" 64
+# bench lines kept beside the profiles: the default line, 32 / 64 clips per launch, the tiled long clip, VALU : MFMA per GEMM launch
+run python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+run python bench.py --clips-per-gpu 32 --steps 640 --warmup 64 --no-cpu-baseline > $O/${TAG}_bench_clips32.json 2> /dev/null
+run python bench.py --clips-per-gpu 64 --steps 1280 --warmup 128 --no-cpu-baseline > $O/${TAG}_bench_clips64.json 2> /dev/null
+run python bench.py --tile-bars --steps 40 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_tile_bars.json 2> /dev/null
+run rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmcv -- python bench.py --clips-per-gpu 64 --steps 128 --warmup 64 --no-cpu-baseline --no-roofline > /dev/null 2> $O/${TAG}_pmcv.err
+python tools/pmc_kernel.py $O/pmcv > $O/${TAG}_pmc_valu_mfma_64_clips.txt 2>&1
 python tools/step_profile.py > $O/${TAG}_step_profile_single_iteration.txt 2>&1
 python tools/step_profile.py 4 16 4 64 > $O/${TAG}_step_profile_64_clips.txt 2>&1
-rm -rf $O/p1 $O/p64 $O/pm1_* $O/pm64_*
+rm -rf $O/p1 $O/p64 $O/pm1_* $O/pm64_* $O/pmcv
 ls -la $O | grep ${TAG}_ | head -30
