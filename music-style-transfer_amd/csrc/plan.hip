@@ -226,6 +226,10 @@ struct mst_plan {
     CombineDesc* d_combines = nullptr; NotesDesc* d_notes = nullptr;     // d_notes: the scheduled (per-clip) copies, s_notes
     SlabEntry* d_slabs[3] = {nullptr, nullptr, nullptr};
     std::vector<SlabBlock> slab_blocks[3]; SlabBlock* d_slab_blocks[3] = {nullptr, nullptr, nullptr};
+    // all three stages' entries as ONE launch (a whole-model backward): valid when no parameter range is the target of two entries
+    std::vector<SlabEntry> slabs_all; SlabEntry* d_slabs_all = nullptr;
+    std::vector<SlabBlock> slab_blocks_all; SlabBlock* d_slab_blocks_all = nullptr;
+    bool slabs_all_ok = false;
     T t_losses, t_saved, t_gl; int64_t loss_scratch = 0;
     std::vector<ZeroChunk> zero_stage[3], zero_all;      // gradient ranges mst_zero_grads clears (clip 0 coordinates)
     ZeroChunk* d_zero_stage[3] = {nullptr, nullptr, nullptr}; ZeroChunk* d_zero_all = nullptr;
@@ -1528,6 +1532,40 @@ int mst_plan::upload() {
             for (int st = 0; st < slabs[s][i].count; st += 64) slab_blocks[s].push_back(SlabBlock{(int)i, st});
         e |= up(slab_blocks[s], &d_slab_blocks[s]);
     }
+    {   // one list for the whole-model backward; two workgroups must never add into the same parameter element concurrently
+        std::vector<std::pair<int64_t, int64_t>> spans;
+        for (int s = 0; s < 3; ++s)
+            for (auto& ent : slabs[s]) {
+                const int64_t hi = ent.width > 0 ? ent.dst + (int64_t)(ent.count / ent.width - 1) * ent.dst_ld + ent.width : ent.dst + ent.count;
+                spans.push_back({ent.dst, hi});
+                slabs_all.push_back(ent);
+            }
+        slabs_all_ok = true;
+        std::vector<std::pair<int64_t, int64_t>> sorted_spans = spans;
+        std::sort(sorted_spans.begin(), sorted_spans.end());
+        for (size_t i = 1; i < sorted_spans.size(); ++i)
+            if (sorted_spans[i].first < sorted_spans[i - 1].second) {
+                // column blocks of one weight matrix interleave inside a bounding span: accept only exact 2-D disjointness
+                slabs_all_ok = false;
+            }
+        if (!slabs_all_ok) {          // precise check: element sets of 2-D entries (rows of `width` at stride dst_ld)
+            slabs_all_ok = true;
+            for (size_t i = 0; i < slabs_all.size() && slabs_all_ok; ++i)
+                for (size_t j = i + 1; j < slabs_all.size() && slabs_all_ok; ++j) {
+                    const SlabEntry& x = slabs_all[i]; const SlabEntry& y = slabs_all[j];
+                    if (spans[i].second <= spans[j].first || spans[j].second <= spans[i].first) continue;
+                    // overlapping bounding spans: disjoint only if both are blocks of the same row pitch with disjoint column ranges
+                    if (!(x.width > 0 && y.width > 0 && x.dst_ld == y.dst_ld)) { slabs_all_ok = false; break; }
+                    const int64_t cx = x.dst % x.dst_ld, cy = y.dst % y.dst_ld;      // column offsets modulo the pitch (same base matrix)
+                    const int64_t bx = x.dst - cx, by = y.dst - cy;
+                    if ((bx - by) % x.dst_ld != 0 || !(cx + x.width <= cy || cy + y.width <= cx)) slabs_all_ok = false;
+                }
+        }
+        for (size_t i = 0; i < slabs_all.size(); ++i)
+            for (int st = 0; st < slabs_all[i].count; st += 64) slab_blocks_all.push_back(SlabBlock{(int)i, st});
+        e |= up(slabs_all, &d_slabs_all);
+        e |= up(slab_blocks_all, &d_slab_blocks_all);
+    }
     return e ? MST_ERR_ALLOC : MST_OK;
 }
 
@@ -1568,6 +1606,7 @@ extern "C" void mst_plan_destroy(mst_plan* p) {
     for (int st = 0; st < 3; ++st) hipFree(p->d_zero_stage[st]);
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
+    hipFree(p->d_slabs_all); hipFree(p->d_slab_blocks_all);
     delete p;
 }
 
@@ -1683,6 +1722,8 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
         int e = run_pass(p, p->list(mask, 1), mask, b, (hipStream_t)stream);
         if (e) return e;
     }
+    if ((mask & MST_STAGE_ALL) == MST_STAGE_ALL && p->slabs_all_ok)      // whole model: the three stages' reductions in one launch
+        return launch_slab_reduce(p->d_slabs_all, p->d_slab_blocks_all, (int)p->slab_blocks_all.size(), b, (hipStream_t)stream) ? MST_ERR_LAUNCH : MST_OK;
     for (int s = 2; s >= 0; --s) {
         if (!((mask >> s) & 1)) continue;
         if (launch_slab_reduce(p->d_slabs[s], p->d_slab_blocks[s], (int)p->slab_blocks[s].size(), b, (hipStream_t)stream))
