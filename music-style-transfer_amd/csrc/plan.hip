@@ -253,6 +253,13 @@ struct mst_plan {
     struct Phase { int what; int pass; int begin, end; int xchg; };        // what: 0 schedule steps, 1 loss partials, 2 loss tail + seed
     std::vector<Phase> phases;
     int K() const { return d.clips > 1 ? d.clips : 1; }
+#ifndef HIPSIM
+    static int device_cus() {          // compute units of the current device (256 on MI355X in SPX mode)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return cus;
+    }
+#endif
     int64_t ext0_stride() const { return (int64_t)P() * NF * NPN * NPF; }
     int64_t ext1_stride() const { return (int64_t)Q() * NF * NUN * NUF; }
     // offset of clip k's slice of `space` relative to clip 0's
@@ -521,8 +528,9 @@ struct mst_plan {
             l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
 #ifndef HIPSIM      // the interpreter runs workgroups one after another: a kernel whose workgroups wait for each other cannot run there
             // the LSTM_NB workgroups of a sequence wait for each other, so every workgroup of the launch must be resident at once:
-            // one group per clip, at most 768 workgroups (256 CUs x 3; the kernels fit 4 per CU) — i.e. up to 64 clips per launch
-            l.multi = (LSTM_NB * K() <= 768 && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
+            // one group per clip, at most 3 workgroups per CU (the kernels fit 4) — up to 64 clips per launch on 256 CUs
+            // (3 workgroups per CU of the device the plan is created on: 768 on a whole MI355X, fewer on a partition)
+            l.multi = (LSTM_NB * K() <= 3 * device_cus() && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
 #endif
             l.xch_off = l.multi ? tmp(2 * (2 * H + 2 * 4 * H)) : 0;
             lstms.push_back(l);
