@@ -22,6 +22,29 @@ instrument_size = len(_group_categories) + len(_instrument_categories)   # 51
 percussion_id = len(included_instruments)
 
 
+class CategoryOneHot:
+    """The slice of sklearn's OneHotEncoder(sparse=False, categories='auto') the reference's callers use (style/data.py:23-27,
+    124-125; style/style_transfer.py:115): `categories_`, `transform` of an (n, 1) column, `inverse_transform` of (n, k) rows."""
+
+    def __init__(self, categories):
+        self.categories_ = [np.array(categories)]
+        self._index = {c: i for i, c in enumerate(categories)}
+
+    def transform(self, column):
+        column = np.asarray(column).reshape(-1)
+        out = np.zeros((len(column), len(self._index)))
+        for i, v in enumerate(column.tolist()):
+            out[i, self._index[v]] = 1.
+        return out
+
+    def inverse_transform(self, rows):
+        return self.categories_[0][np.asarray(rows).argmax(1)].reshape(-1, 1)
+
+
+instruments_one_hot_encoder = CategoryOneHot(_instrument_categories)
+groups_one_hot_encoder = CategoryOneHot(_group_categories)
+
+
 def iter_all_midis(files, shuffle=False, looped=False):
     """(file, channels, info) of every readable file; unreadable files and MidiFormatErrors are skipped."""
     if shuffle:

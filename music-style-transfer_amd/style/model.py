@@ -264,7 +264,7 @@ class StyleTransferModel(nn.Module):
             raise _native.MstError(f'layer widths {widths} are outside the instantiated HIP kernels '
                                    '(melody_size must be 8 or 4; LSTM hidden sizes <= 256)')
         self._flat = self._gflat = None
-        self._offsets = self._ends = None
+        self._offsets = self._ends = self._slots = None
         self.graph_repeated_shapes = True       # train_iteration(): replay a hipGraph when a clip shape comes back
 
     def _link_children(self):
@@ -280,12 +280,17 @@ class StyleTransferModel(nn.Module):
     def _sync_flat(self):
         """Point every Parameter's storage into ONE flat fp32 buffer laid out as the C ABI expects
         (model.parameters() order).  Re-done if the parameters moved (.to(), load_state_dict of new tensors)."""
-        # fast path (every forward of a training loop): the first and the last parameter still alias the flat buffer where
-        # they should.  Whatever re-homes parameters (.to(), load_state_dict(assign=True), ...) moves them all.
+        # fast path (every forward of a training loop): every Parameter OBJECT registered in the module tree is still the one
+        # that was aliased into the flat buffer (identity against the leaf modules' own `_parameters` dicts: catches
+        # load_state_dict(assign=True) and `module.weight = nn.Parameter(...)` anywhere in the tree, which install new objects
+        # while the old ones keep aliasing the flat buffer), and the first and the last of them still point where they should
+        # (catches .to(), which re-homes the data of all of them)
         ends = getattr(self, '_ends', None)
-        if self._flat is not None and ends is not None:
+        slots = getattr(self, '_slots', None)
+        if self._flat is not None and ends is not None and slots is not None:
             base = self._flat.data_ptr()
-            if ends[0][0].data_ptr() == base + 4 * ends[0][1] and ends[1][0].data_ptr() == base + 4 * ends[1][1]:
+            if (all(reg.get(key) is p for reg, key, p in slots) and ends[0][0].data_ptr() == base + 4 * ends[0][1]
+                    and ends[1][0].data_ptr() == base + 4 * ends[1][1]):
                 return
         named = list(self.named_parameters())
         dev = named[0][1].device
@@ -294,6 +299,7 @@ class StyleTransferModel(nn.Module):
         if self._flat is not None and self._flat.device == dev and all(
                 p.data_ptr() == self._flat.data_ptr() + 4 * off for (_, p), off in zip(named, self._offsets)):
             self._ends = ((named[0][1], self._offsets[0]), (named[-1][1], self._offsets[-1]))
+            self._slots = self._param_slots()
             return
         table = _native.get().param_table(_dims(**self._widths))
         if [n for n, _ in named] != [n for n, _, _ in table]:
@@ -307,6 +313,11 @@ class StyleTransferModel(nn.Module):
         self._flat, self._gflat = flat, torch.zeros_like(flat)
         self._offsets = [off for _, off, _ in table]
         self._ends = ((named[0][1], self._offsets[0]), (named[-1][1], self._offsets[-1]))
+        self._slots = self._param_slots()
+
+    def _param_slots(self):
+        """(leaf module's `_parameters` dict, key, Parameter) for every parameter, in model.parameters() order."""
+        return [(mod._parameters, key, p) for mod in self.modules() for key, p in mod._parameters.items() if p is not None]
 
     def _grad_target(self):
         """Where backward accumulates: the flat gradient buffer, aliased by every p.grad."""

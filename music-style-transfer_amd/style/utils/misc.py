@@ -30,6 +30,35 @@ def flatten_underscore(d, prefix=''):
     return out
 
 
+def _hashable(obj):
+    if isinstance(obj, (list, tuple)):
+        return tuple(_hashable(o) for o in obj)
+    return frozenset(obj) if isinstance(obj, set) else obj
+
+
+def group_by(data, key=None, attr=None, func=None, save_indices=False):
+    """Buckets of `data` in first-seen key order (style/utils/misc.py:93-113, used by style/data.py:69): the key is a
+    callable, an item name (`key='name'`), an attribute name (`attr=`) or the element itself; `save_indices` collects
+    positions instead of elements; `func` maps every bucket."""
+    if callable(key):
+        key_of = key
+    elif key:
+        key_of = lambda x: x[key]                # noqa: E731
+    elif attr:
+        key_of = lambda x: getattr(x, attr)      # noqa: E731
+    else:
+        key_of = lambda x: x                     # noqa: E731
+    buckets = {}
+    for i, elem in enumerate(data):
+        buckets.setdefault(_hashable(key_of(elem)), []).append(i if save_indices else elem)
+    return {k: func(v) for k, v in buckets.items()} if func else buckets
+
+
+def flatten(elems):
+    """One level of nesting removed (style/utils/misc.py:116-117)."""
+    return [x for sub in elems for x in sub]
+
+
 def make_dirs(path):
     os.makedirs(path or '.', exist_ok=True)
 

@@ -224,12 +224,51 @@ def inference_case():
     print('inference: bpm', float(bp), 'hard ones', float(hp[..., 2:].sum()), len(out), 'arrays')
 
 
+def loss_case():
+    """get_total_loss on its own (style/model.py:935-997) with normalize=False — the reference's DEFAULT, which its training
+    script overrides — and normalize=True, on free-standing predictions (not model outputs): every loss leaf and the gradient
+    of `total` with respect to each prediction, with and without the unpitched pair.  Called with the positional contract of
+    train-model.py:115-122 (bpm before mode)."""
+    C, R, T = 2, 2, 2
+    clip = synth_clip(4, C, R, T, True, density=0.08)
+    g = torch.Generator().manual_seed(21)
+    pp = torch.rand(clip['pitched'].shape, generator=g) * .98 + .01          # accidentals go through BCE: keep inside (0, 1)
+    pp[..., 0] = pp[..., 0] * 6                                              # durations live in (0, 6)
+    up = torch.rand(clip['unpitched'].shape, generator=g) * .98 + .01
+    up[..., 0] = up[..., 0] * 6
+    il = torch.randn(1, N_INSTRUMENTS, generator=g)
+    ml = torch.randn(1, 2, generator=g)
+    bp = torch.tensor([97.5])
+    out = dict(crt=np.array([C, R, T]), density=np.array(0.08), clip_id=np.array(4))
+    out.update({'in/pitched_pred': pp.numpy().copy(), 'in/unpitched_pred': up.numpy().copy(), 'in/instruments': il.numpy().copy(),
+                'in/mode': ml.numpy().copy(), 'in/bpm': bp.numpy().copy()})
+    for normalize in (False, True):
+        for unp in (True, False):
+            leaves = [t.clone().requires_grad_(True) for t in (pp, up, il, ml, bp)]
+            a, b, c, d, e = leaves
+            losses = ref.get_total_loss(c, clip['used_instruments'], e, clip['bpm_int'], d, clip['mode'], a, clip['pitched'],
+                                        b if unp else None, clip['unpitched'] if unp else None, normalize=normalize)
+            losses['total'].backward()
+            tag = f'n{int(normalize)}u{int(unp)}'
+            for k, v in flat_losses(losses).items():
+                out[f'{tag}/loss/{k}'] = np.array(v)
+            for name, t in zip(('pitched_pred', 'unpitched_pred', 'instruments', 'mode', 'bpm'), leaves):
+                if t.grad is not None:
+                    out[f'{tag}/grad/{name}'] = t.grad.numpy().copy()
+            print(tag, 'total', float(losses['total']))
+    np.savez_compressed(os.path.join(HERE, 'loss_normalize.npz'), **out)
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['inference']:          # added later: leaves the earlier fixtures untouched
         inference_case()
+        sys.exit(0)
+    if sys.argv[1:] == ['loss']:
+        loss_case()
         sys.exit(0)
     small_case('small_unpitched', True)
     small_case('small_pitched_only', False)
     full_case()
     trajectory_case()
     inference_case()
+    loss_case()

@@ -135,12 +135,19 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
     gc = gparams.cpu()
     e = rel(gc.numpy(), gref.numpy())
     assert e < TOL, ('all gradients', e)
-    worst = 0.0
+    # per tensor: the north_star bar (1e-4 rel-L2) for every tensor that carries more than 1 % of the gradient norm; tensors
+    # below that are dominated by fp32 cancellation in long sums (their absolute error is far under the bar of the whole
+    # vector) and get a loose guard against structural mistakes only
+    worst, worst_big = 0.0, 0.0
     for pname, off, shape in table:
         n = int(np.prod(shape))
         r = gref[off:off + n]
         if float(r.norm()) > 1e-7 * float(gref.norm()):
-            worst = max(worst, rel(gc[off:off + n].numpy(), r.numpy()))
+            err = rel(gc[off:off + n].numpy(), r.numpy())
+            worst = max(worst, err)
+            if float(r.norm()) > 1e-2 * float(gref.norm()):
+                worst_big = max(worst_big, err)
+                assert err < TOL, ('per-tensor gradient (> 1 % of the norm)', pname, err)
     assert worst < 2e-3, ('worst per-tensor gradient', worst)
     if check_bitwise:   # fixed summation order everywhere: a second run must be bit-identical
         g2 = torch.zeros_like(params)
@@ -204,3 +211,50 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
                       for n, _, _ in table])
     e = rel(gK.cpu().numpy(), gref.numpy())
     assert e < TOL, ('summed gradients', e)
+
+
+def loss_normalize_case(native, device):
+    """get_total_loss on its own through mst_total_loss_fwd / _bwd against the reference-generated fixture
+    tests/golden/loss_normalize.npz: normalize = False (the reference's default, style/model.py:937) and True, with and
+    without the unpitched pair — every loss leaf and the gradient of `total` with respect to every prediction."""
+    z = np.load(os.path.join(GOLDEN, 'loss_normalize.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    clip = synth_clip(int(z['clip_id']), C, R, T, True, density=float(z['density']))
+    lib = native.lib
+    f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).contiguous().to(device)
+    pp, up, il, ml, bp = (f(z['in/' + k]) for k in ('pitched_pred', 'unpitched_pred', 'instruments', 'mode', 'bpm'))
+    pt, ut, it, mt = f(clip['pitched']), f(clip['unpitched']), f(clip['used_instruments']), f(clip['mode'])
+    bt = f([float(clip['bpm_int'])])
+    P = nat.ptr
+    stream = nat.current_stream(device)
+    for normalize in (0, 1):
+        for unp in (1, 0):
+            tag = f'n{normalize}u{unp}'
+            losses = torch.full((nat.N_LOSSES,), -7., device=device)
+            saved = torch.zeros(nat.LOSS_SAVED, device=device)
+            scratch = torch.full((lib.mst_loss_scratch_floats(),), float('nan'), device=device)
+            n_p, n_u = pp.numel() // 5, (up.numel() // 2 if unp else 0)
+            upx, utx = (up, ut) if unp else (None, None)
+            nat.check(lib.mst_total_loss_fwd(P(pp), P(pt), n_p, P(upx), P(utx), n_u, P(il), P(it), il.numel(), P(ml), P(mt), P(bp),
+                                             P(bt), normalize, P(losses), P(saved), P(scratch), stream), 'mst_total_loss_fwd')
+            lc = losses.cpu()
+            for i, k in enumerate(nat.LOSS_KEYS):
+                key = f'{tag}/loss/{k}'
+                if key in z.files:
+                    assert abs(float(lc[i]) - float(z[key])) < 2e-5 * max(1., abs(float(z[key]))), (tag, k, float(lc[i]), float(z[key]))
+                else:
+                    assert np.isnan(float(lc[i])), (tag, k)
+            gl = torch.zeros(nat.N_LOSSES, device=device)
+            gl[0] = 1.
+            nanf = lambda t: torch.full_like(t, float('nan'))
+            g_pp, g_il, g_ml, g_bp = nanf(pp), nanf(il), nanf(ml), nanf(bp)
+            g_up = nanf(up) if unp else None
+            nat.check(lib.mst_total_loss_bwd(P(pp), P(pt), n_p, P(upx), P(utx), n_u, P(il), P(it), il.numel(), P(ml), P(mt), P(bp),
+                                             P(bt), P(saved), P(gl), P(g_pp), P(g_up), P(g_il), P(g_ml), P(g_bp), stream),
+                      'mst_total_loss_bwd')
+            got = dict(pitched_pred=g_pp, instruments=g_il, mode=g_ml, bpm=g_bp)
+            if unp:
+                got['unpitched_pred'] = g_up
+            for name, g in got.items():
+                e = rel(g.cpu().numpy(), z[f'{tag}/grad/{name}'])
+                assert e < TOL, (tag, name, e)

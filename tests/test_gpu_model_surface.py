@@ -304,3 +304,31 @@ def test_hard_output_matches_oracle_and_mutates_input():
     assert torch.equal(xd[..., 1].cpu(), ref[..., 1])       # velocities zeroed in place, like the reference
     xu = torch.rand(1, 1, 2, 3, 10, 47, 2)
     assert torch.equal(m.hard_output(xu.to(DEV)).cpu(), so.hard_output(xu.clone()))
+
+
+def test_replaced_parameter_objects_are_picked_up():
+    """load_state_dict(assign=True) and `module.weight = nn.Parameter(...)` install NEW Parameter objects while the old ones
+    keep aliasing the flat buffer the kernels read: the next forward must run on the new weights."""
+    z, model = load_small('small_unpitched')
+    C, R, T = (int(v) for v in z['crt'])
+    clip = to_dev(synth_clip(0, C, R, T, True, density=float(z['density'])))
+    with torch.no_grad():
+        (ip, _, _), xp, _ = model(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+    assert rel(xp.cpu(), z['out/pitched']) < 1e-4
+    # (a) every parameter replaced through load_state_dict(assign=True): the post-Adam parameters of the fixture
+    sd = {k: torch.from_numpy(z['p1/' + k]).to(DEV) for k in model.state_dict()}
+    model.load_state_dict(sd, assign=True)
+    other = build_model(SMALL)
+    other.load_state_dict({k: torch.from_numpy(z['p1/' + k]) for k in other.state_dict()})
+    other = other.to(DEV)
+    with torch.no_grad():
+        (ip1, _, _), xp1, _ = model(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+        (ip2, _, _), xp2, _ = other(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+    assert torch.equal(xp1, xp2) and torch.equal(ip1, ip2) and not torch.equal(xp1, xp)
+    # (b) ONE parameter in the middle of the tree replaced by attribute assignment
+    lin = model.song_info_model.instruments_linear
+    lin.bias = torch.nn.Parameter(lin.bias.detach() + 3.)
+    with torch.no_grad():
+        (ip3, _, _), xp3, _ = model(clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'])
+    assert torch.allclose(ip3, ip1 + 3., atol=1e-5) and torch.equal(xp3, xp1)
+    assert all(p.data_ptr() == model._flat.data_ptr() + 4 * off for p, off in zip(model.parameters(), model._offsets))

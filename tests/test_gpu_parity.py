@@ -25,6 +25,10 @@ def test_oracle_small_widths_ragged_shapes(native, C, R, T, unp):
     pc.oracle_case(native, torch.device('cuda:0'), pc.SMALL, C, R, T, unp, density=0.05, check_bitwise=True)
 
 
+def test_total_loss_normalize_false_and_true_against_reference_fixture(native):
+    pc.loss_normalize_case(native, torch.device('cuda:0'))
+
+
 def test_oracle_full_widths_small_clip(native):
     pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 2, 2, 4, True, check_bitwise=True)
 

@@ -129,6 +129,29 @@ def test_two_clip_gradient_sum_against_reference_fixture():
             assert rel(p.grad, ref) < 2e-4, n
 
 
+def test_total_loss_normalize_false_and_true_against_reference_fixture():
+    z = np.load(os.path.join(GOLDEN, 'loss_normalize.npz'))
+    C, R, T = (int(v) for v in z['crt'])
+    clip = synth_clip(int(z['clip_id']), C, R, T, True, density=float(z['density']))
+    for normalize in (0, 1):
+        for unp in (1, 0):
+            tag = f'n{normalize}u{unp}'
+            leaves = {k: torch.tensor(z['in/' + k]).requires_grad_(True) for k in ('pitched_pred', 'unpitched_pred', 'instruments', 'mode', 'bpm')}
+            out = so.total_loss(leaves['instruments'], clip['used_instruments'], leaves['bpm'], clip['bpm_int'], leaves['mode'], clip['mode'],
+                                leaves['pitched_pred'], clip['pitched'], leaves['unpitched_pred'] if unp else None,
+                                clip['unpitched'] if unp else None, normalize=bool(normalize))
+            keys = [k[len(tag) + 6:] for k in z.files if k.startswith(tag + '/loss/')]
+            assert sorted(keys) == sorted(out), tag
+            for k in keys:
+                assert abs(float(out[k]) - float(z[f'{tag}/loss/{k}'])) < 1e-5, (tag, k)
+            out['total'].backward()
+            for name, t in leaves.items():
+                if f'{tag}/grad/{name}' in z.files:
+                    assert rel(t.grad, z[f'{tag}/grad/{name}']) < 1e-5, (tag, name)
+                else:
+                    assert t.grad is None, (tag, name)
+
+
 def test_hard_output():
     x = torch.rand(1, 2, 2, 2, 10, 56, 5)
     y = so.hard_output(x.clone())

@@ -64,3 +64,7 @@ def test_single_clip_on_the_mfma_gemm(monkeypatch):
     monkeypatch.setenv('MST_GEMM', 'mfma')
     pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True)
     pc.golden_small(sim_native(), 'cpu', 'small_unpitched')
+
+
+def test_total_loss_normalize_false_and_true_against_reference_fixture():
+    pc.loss_normalize_case(sim_native(), 'cpu')

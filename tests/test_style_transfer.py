@@ -16,6 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MIDI = os.path.join(HERE, 'golden', 'midi')
 COMPOSITION = os.path.join(MIDI, 'Minuetto in sol magg. BWV App. 114.mid')
 STYLE = os.path.join(MIDI, 'Nocturne No. 1 in E minor, Op. 72_ Andante.mid')
+# two of the reference's examples WITH a percussion channel (5 + 1 and 4 + 1 channels): the unpitched encoders, the unpitched
+# applier, hard_output on 2-feature rolls and the key - 35 drum decoding (style/midi_conversion.py:605-609) end to end
+DRUMS_COMPOSITION = os.path.join(MIDI, 'Dancing in the Moonlight.mid')
+DRUMS_STYLE = os.path.join(MIDI, 'Angie.4.mid')
 
 
 def test_select_instruments():
@@ -62,7 +66,10 @@ def _events(track):
 
 
 @pytest.mark.gpu
-def test_transfer_style_end_to_end(tmp_path):
+@pytest.mark.parametrize('composition,style_song,drums', [(COMPOSITION, STYLE, False), (DRUMS_COMPOSITION, DRUMS_STYLE, True)],
+                         ids=['piano_pair', 'percussion_pair'])
+def test_transfer_style_end_to_end(tmp_path, composition, style_song, drums):
+    COMPOSITION, STYLE = composition, style_song
     from oracle import style_oracle as so
     from style import smf, style_transfer as st
     from style.data import prepare_input, encode_instruments
@@ -70,9 +77,15 @@ def test_transfer_style_end_to_end(tmp_path):
     from style.scales import major_mode, minor_mode
     from test_host_surface import FULL, build_model
     model = build_model(FULL, seed=108).to('cuda:0')
+    if drums:
+        # the randomly initialised model has no reason to rank percussion among its top picks: lift its logit so that
+        # style/style_transfer.py:105-116 selects it and the unpitched applier runs (the oracle below reads the same parameters)
+        from style.data import percussion_id
+        with torch.no_grad():
+            model.song_info_model.instruments_linear.bias[percussion_id] += 10.
     out = str(tmp_path)
     st.transfer_style(model, COMPOSITION, [STYLE], out)
-    name, sname = 'Minuetto in sol magg. BWV App. 114', 'Nocturne No. 1 in E minor, Op. 72_ Andante'
+    name, sname = (os.path.splitext(os.path.basename(p))[0] for p in (COMPOSITION, STYLE))
     base = os.path.join(out, name)
     files = {k: os.path.join(base, v) for k, v in dict(
         original=f'original/{name}.mid', style_original=f'original/{sname}.mid', reconstructed=f'{name} (reconstructed).mid',
@@ -83,13 +96,19 @@ def test_transfer_style_end_to_end(tmp_path):
     # notes hard_output silences (velocity <= .01, i.e. MIDI velocity 1 after the 96/127 volume scaling)
     for k, src in (('original', COMPOSITION), ('style_original', STYLE)):
         _, (info, pitched, _, instruments, unpitched) = st.get_model_input(src)
-        assert unpitched is None
+        assert (unpitched is not None) == drums
         hard = so.hard_output(torch.tensor(pitched, dtype=torch.float).unsqueeze(0)).numpy()[0]
-        want = st.decode_rolls(ChannelConverter(info), st.channel_slots(instruments)[0], hard)
+        hard_u = so.hard_output(torch.tensor(unpitched, dtype=torch.float).unsqueeze(0)).numpy()[0, 0] if drums else None
+        # `save` trims the channel infos to shape[1] of the numpy rolls (= the bar count: reference quirk, kept)
+        infos, uinfo = st.channel_slots(instruments)
+        want = st.decode_rolls(ChannelConverter(info), infos[:pitched.shape[1]], hard, uinfo if drums else None, hard_u)
         got = smf.MidiFile(files[k])
         assert got.to_bytes() == want.to_bytes(), k
         a, b = _events(got.tracks[0]), _events(smf.MidiFile(src).tracks[0])
-        assert not a - b and sum((b - a).values()) <= 4, k
+        if drums:
+            assert any(key[3] == -1 for key in a), k             # percussion events (channel 9) were written
+        else:
+            assert not a - b and sum((b - a).values()) <= 4, k
 
     # oracle: same host code, torch-CPU model arithmetic
     flat = {n: p.detach().cpu() for n, p in model.named_parameters()}
@@ -119,6 +138,7 @@ def test_transfer_style_end_to_end(tmp_path):
     want = {'reconstructed': oracle_apply(cinfo, style_a, melody_a, rhythm_a, len(cinstr))}
     want['styled'] = oracle_apply(st.combine_info(style_info=sinfo, melody_info=cinfo), style_b, melody_a, rhythm_a, len(sinstr))
     for k, (mid, programs, unpitched) in want.items():
+        assert unpitched == drums, k
         got = smf.MidiFile(files[k])
         head = lambda m: [(x.type, x.__dict__.get('tempo'), x.__dict__.get('program'), x.__dict__.get('numerator'))
                           for x in m.tracks[0] if x.type in ('set_tempo', 'program_change', 'time_signature')]
