@@ -45,6 +45,28 @@ def algorithmic_flops_per_iter(C, R, T, U=1):
     return 3 * fwd
 
 
+N_PARAMS = 980325
+
+
+def algorithmic_bytes_per_iter(C, R, T, iter_size, U=1):
+    """SURVEY.md §8(d), fused ideal, fp32: the note tensors read twice (encode + loss target) and the prediction written once,
+    melody / rhythm written + read, plus the parameter traffic of an optimizer step (read fwd + read bwd + gradient write = 3x,
+    Adam reads p, g, m, v and writes p, m, v = 7x: 10 x 4 B x 980 325 = 39.2 MB) AMORTISED over the iter_size clip-iterations
+    that share the step (train-model.py:95,151-154): 11.8 + 39.2 / iter_size MB for the bench clip."""
+    P, Q = C * R * T, R * T
+    per_clip = 3 * 11200 * P + U * 3 * 3760 * Q + (17920 + 1280) * 2 * Q
+    return per_clip + 10 * 4 * N_PARAMS / iter_size
+
+
+def pmc_traffic_per_iteration(clips=1):
+    """HBM bytes per clip-iteration over ALL kernels of the timed loop, from the committed rocprofv3 --pmc passes, or None."""
+    path = _latest_profile('pmc_hbm_traffic.json' if clips == 1 else f'pmc_hbm_traffic_{clips}_clips.json')
+    try:
+        return float(json.load(open(path))['per_iteration']['hbm_bytes'])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def init_params(native, dims, seed=108):
     """Random-init weights of the reference architecture (uniform +-1/sqrt(fan_in), like nn.Linear)."""
     table = native.param_table(dims)
@@ -115,7 +137,7 @@ def rocprof_avg_us(kernel, clips=1):
     return None
 
 
-def roofline_leg(plan, nat, params, gparams, xp, xu, K, dt_per_clip_iter, breakdown=False):
+def roofline_leg(plan, nat, params, gparams, xp, xu, K, dt_per_clip_iter, breakdown=False, iter_size=None):
     """Every launch step of one pass timed with HIP events on the current stream (mst_plan_time_steps: 20 back-to-back
     launches of the step on an otherwise idle GPU), aggregated per kernel; the roofline object is for the kernel with
     the largest share.  achieved = sum of its descriptors' algorithmic FLOPs / sum of its launch durations."""
@@ -145,6 +167,14 @@ def roofline_leg(plan, nat, params, gparams, xp, xu, K, dt_per_clip_iter, breakd
                 frac_from_rocprof=(fl / cnt / (prof_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if prof_us else None,
                 whole_iteration=dict(algorithmic_gflop=algorithmic_flops_per_iter(**CLIP) / 1e9,
                                      achieved_tflops=algorithmic_flops_per_iter(**CLIP) / dt_per_clip_iter / 1e12))
+    # whole clip-iteration against the HBM roof: algorithmic bytes with the optimizer step's parameter traffic amortised over
+    # the iter_size clip-iterations that share it, beside the PMC-measured bytes of every kernel of the loop
+    ab = algorithmic_bytes_per_iter(**CLIP, iter_size=iter_size or max(K, ITER_SIZE))
+    tb = pmc_traffic_per_iteration(K)
+    roof.update(algorithmic_bytes=ab, traffic_per_iteration=tb, traffic_ratio=(tb / ab) if tb else None,
+                algorithmic_bytes_note='per clip-iteration, whole loop body; 11.8 MB of note / melody / rhythm traffic + 39.2 MB of '
+                                       'parameter + Adam traffic per optimizer step / iter_size; traffic_per_iteration = FETCH_SIZE + '
+                                       'WRITE_SIZE of all kernels (profiles/, raw counters: 16-byte loads are under-reported)')
     if breakdown:
         for r in rows:
             print(json.dumps(r), file=sys.stderr)
@@ -184,14 +214,19 @@ def batched_leg(native, nat, dev, flat, K, passes, warm):
             one_pass()
         for _ in range(warm):
             graph.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(passes):
-            graph.replay()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        roof, rows = roofline_leg(plan, nat, params, g, xp, xu, K, dt / (passes * K))
+        times = []
+        while len(times) < 3 or (sum(times) < 0.25 and len(times) < 50):      # >= 3 regions of `passes` passes, >= 0.25 s in all
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                graph.replay()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        dt = float(np.median(times))
+        roof, rows = roofline_leg(plan, nat, params, g, xp, xu, K, dt / (passes * K), iter_size=K)
     return dict(value=passes * K / dt, unit='clip-iterations/s', ms_per_pass=dt / passes * 1e3, passes=passes, warmup_passes=warm,
+                spread=dict(repeats=len(times), min_ms_per_pass=min(times) / passes * 1e3, max_ms_per_pass=max(times) / passes * 1e3,
+                            value='median over the repeats'),
                 config=dict(workload=f'{K} different 30 s clips (C=4,R=16,T=4 +percussion) on one GPU in one batched plan '
                                      f'(BASELINE.json configs[2]): fwd+loss+bwd of all {K} clips per pass, gradients summed, '
                                      'Adam+StepLR after every pass', clips_per_launch=K, iter_size=K, hip_graph=True,

@@ -82,7 +82,12 @@ typedef struct {
                                  * the per-position work of bars [tile_r0, tile_r0 + tile_rows) of the mst_dims.R bars; the bar-level
                                  * chains run replicated.  tile_rows = 0: not tiled.  Run with mst_tiled_phase (clips must be 1);
                                  * `pitched` / `unpitched` are then the tile's bars only: (1,C,tile_rows,T,10,56,5), (1,1,tile_rows,T,10,47,2) */
-    int32_t reserved[3];        /* must be 0 */
+    int32_t lstm_flavour;       /* StyleEncoder.bars_lstm (H = 192, style/model.py:152,179-181): 0 = choose (the 12-workgroup-per-clip
+                                 * kernels when all of a launch's workgroups fit the device at once with one workgroup slot per CU to spare,
+                                 * else one workgroup per sequence); 1 = always one workgroup per sequence (use it when other kernels are
+                                 * meant to run beside a batched plan); 2 = the 12-workgroup kernels with an injected exchange fault
+                                 * (tests of the mst_plan_status path only) */
+    int32_t reserved[2];        /* must be 0 */
 } mst_plan_options;
 mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
 mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);
@@ -97,6 +102,15 @@ int32_t mst_plan_launch_count(const mst_plan* p, int32_t stage_mask, int32_t bac
 /* out = {clips, activation floats per clip, scratch floats per clip, offset of the gradient arena}.
  * Clip k's copy of a named tensor sits k * out[1] floats after clip 0's (mst_plan_tensor offsets). */
 int32_t mst_plan_layout(const mst_plan* p, int64_t out[4]);
+
+/* ---- device health.  Kernels whose workgroups wait for each other (the 12-workgroup StyleEncoder LSTM) cannot report a
+ * failure through a return code: the launch has long returned.  They OR a bit into a status word inside the workspace
+ * (named tensor "device_status", first element, int32) and produce NaNs from then on; the word is sticky.  mst_plan_status
+ * synchronises `stream`, copies the word to *status and, with clear != 0, resets it.  A training loop that reads its losses back
+ * every N iterations checks it at the same moment (style/train.py LossLog.flush).  No reference counterpart: the reference has
+ * no device-side synchronisation of its own. */
+enum { MST_DEV_OK = 0, MST_DEV_LSTM_TIMEOUT = 1 /* a granule of the LSTM exchange did not arrive within 0.2 s */ };
+int32_t mst_plan_status(const mst_plan* p, float* ws, int32_t clear, int32_t* status, mst_stream stream);
 
 /* ---- forward: StyleTransferModel.extract_style / predict_song_info / apply_style / forward
  * (style/model.py:751-793), selected by stage_mask. `pitched` (1,C,R,T,10,56,5) and
@@ -190,6 +204,10 @@ int32_t mst_plan_step_gemms(const mst_plan* p, int32_t stage_mask, int32_t backw
 int32_t mst_plan_time_steps(const mst_plan* p, int32_t stage_mask, int32_t backward, const float* params,
                             float* gparams, float* ws, const float* pitched, const float* unpitched,
                             mst_stream stream, int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes);
+
+/* test hook of the plan builder's single-launch weight-gradient reduction guard: do two column blocks of one row-major matrix
+ * (row pitch ld), given by their first elements' offsets from the matrix's element (0, 0), share no element?  1 = disjoint. */
+int32_t mst_debug_slab_columns_disjoint(int64_t off_x, int32_t width_x, int64_t off_y, int32_t width_y, int32_t ld);
 
 const char* mst_version(void);
 

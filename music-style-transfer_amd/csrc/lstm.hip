@@ -482,23 +482,52 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_group_kernel(const LstmDesc* 
 // until its tag is this step's epoch — the data is its own flag, no fence, no separate counter
 // (cdna_hip_programming.md Guideline 16, R2).  Buffers alternate with the step's parity: a workgroup can publish step
 // t + 1 only after it has consumed every workgroup's step t, so the slot it overwrites (t - 1) is no longer needed by
-// anyone.  Tags are cleared before every forward (lstm_transpose_kernel): epochs restart at 1 in every launch.  Every spin
-// is bounded: a workgroup that never sees its tag yields NaNs instead of hanging the GPU.
-// The 12 (x 2 concurrent iterations) workgroups are far below the chip's residency, but dispatch order is still undefined:
-// nothing here depends on which workgroup starts first.
-#ifndef HIPSIM
+// anyone.  Tags are cleared before every forward (lstm_transpose_kernel): epochs restart at 1 in every launch.
+// The 12 x clips workgroups of a launch must all be resident at once (the plan sizes the launch from the occupancy the
+// runtime reports for these kernels, lstm_multi_blocks_per_cu(), and keeps one workgroup slot per CU free); dispatch order
+// is undefined and nothing here depends on which workgroup starts first.
+// FAILURE IS LOUD AND BOUNDED: a lane that does not see its tag within LSTM_WAIT_TICKS of wall clock (0.2 s; a healthy wait is
+// microseconds) ORs MST_DEV_LSTM_TIMEOUT into the plan's device status word (LstmDesc.status_off), returns NaN and makes every
+// later wait of that lane return NaN at once; every other waiting lane of the launch looks at the status word every 256 polls
+// and gives up as soon as it is set, so the whole launch drains within a millisecond of the first timeout instead of
+// S x 0.2 s.  The status word is sticky until the host reads and clears it (mst_plan_status); while it is set, every wait of
+// a later launch gives up after 256 polls — nothing computed after a failure looks healthy.
+#ifdef HIPSIM
+#define LSTM_WAIT_TICKS 8            /* the interpreter's clock counts calls: 8 x 256 polls */
+#else
+#define LSTM_WAIT_TICKS 20000000     /* wall_clock64() runs at 100 MHz: 0.2 s */
+#endif
 typedef unsigned long long lstm_gran_t;
 __device__ __forceinline__ void gran_store(lstm_gran_t* g, unsigned tag, float v) {
     __hip_atomic_store(g, ((lstm_gran_t)tag << 32) | (lstm_gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float gran_wait(const lstm_gran_t* g, unsigned tag) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+__device__ __forceinline__ float gran_wait(const lstm_gran_t* g, unsigned tag, int* status, bool& dead) {
+    if (dead) return __builtin_nanf("");
+    long long t0 = 0;
+    for (unsigned spin = 0;; ++spin) {
         const lstm_gran_t x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
         __builtin_amdgcn_s_sleep(1);
+        if ((spin & 255u) == 255u) {                     // off the fast path: a healthy wait ends within a few polls
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;      // somebody gave up
+            const long long now = wall_clock64();
+            if (spin == 255u) t0 = now;
+            else if (now - t0 > LSTM_WAIT_TICKS) { __hip_atomic_fetch_or(status, MST_DEV_LSTM_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
     }
+    dead = true;
     return __builtin_nanf("");
 }
+// LDS of a kernel whose workgroups are co-resident: the interpreter keeps one copy per block (its `__shared__` is a static)
+#ifdef HIPSIM
+#define MST_COOP_LDS(name, n) static float name##_all[hipsim::COOP_MAXB][n]; float* name = name##_all[hipsim::coop_block()]
+#define MST_COOP_LDS2(name, n, m) static float name##_all[hipsim::COOP_MAXB][n][m]; float (*name)[m] = name##_all[hipsim::coop_block()]
+#define MST_LAUNCH_CORESIDENT(k, g, b, s, ...) hipsim::launch_coop((k), (g), (b), (s), __VA_ARGS__)
+#else
+#define MST_COOP_LDS(name, n) __shared__ __attribute__((aligned(16))) float name[n]
+#define MST_COOP_LDS2(name, n, m) __shared__ float name[n][m]
+#define MST_LAUNCH_CORESIDENT(k, g, b, s, ...) hipLaunchKernelGGL((k), (g), (b), 0, (s), __VA_ARGS__)
+#endif
 
 __global__ __launch_bounds__(256) void lstm_multi_fwd_kernel(const LstmDesc* __restrict__ descs, Bases b) {
     const LstmDesc d = descs[blockIdx.y];
@@ -507,13 +536,18 @@ __global__ __launch_bounds__(256) void lstm_multi_fwd_kernel(const LstmDesc* __r
     const int row_l = tid >> 2, kq = tid & 3;                                  // gate row of this workgroup / quarter of k
     const int gate = row_l / HU, u = row_l - gate * HU;
     const int j = gate * H + wg * HU + u;                                      // row of W_hh
-    __shared__ __attribute__((aligned(16))) float h_s[H];
-    __shared__ float z_s[4 * HU];
+    MST_COOP_LDS(h_s, H);
+    MST_COOP_LDS(z_s, 4 * HU);
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* zx = b.p[SP_WS] + d.zx_off;
     float* ws = b.p[SP_WS];
     float* tmp = b.p[SP_TMP];
     lstm_gran_t* xch = reinterpret_cast<lstm_gran_t*>(tmp + d.xch_off);        // [2][H]
+    int* status = reinterpret_cast<int*>(b.p[SP_WS] + d.status_off);
+    bool dead = false;
+    // multi == 2 (mst_plan_options.lstm_flavour = 2, tests only): workgroup 0 publishes its first step under a wrong epoch, so
+    // that every consumer of it runs into the timeout path
+    const unsigned fault = (d.multi == 2 && wg == 0) ? 0x10000u : 0u;
     float w[KQ];
 #pragma unroll
     for (int i = 0; i < KQ / 4; ++i) {
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(256) void lstm_multi_fwd_kernel(const LstmDesc* __r
             for (int q = 0; q < 4; ++q) zn[q] = zx[(int64_t)sn * G + q * H + k];
         }
         // h_{t-1} of every workgroup (tag = step: published with epoch (step - 1) + 1)
-        if (tid < H) h_s[tid] = step == 0 ? 0.f : gran_wait(xch + ((step - 1) & 1) * H + tid, (unsigned)step);
+        if (tid < H) h_s[tid] = step == 0 ? 0.f : gran_wait(xch + ((step - 1) & 1) * H + tid, (unsigned)step, status, dead);
         __syncthreads();
         if (tid < HU) hprev = h_s[k];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -559,7 +593,7 @@ __global__ __launch_bounds__(256) void lstm_multi_fwd_kernel(const LstmDesc* __r
             c = fg * c + ig * gg;
             const float tc = tanh_fast(c);
             const float h = og * tc;
-            gran_store(xch + (step & 1) * H + k, (unsigned)(step + 1), h);      // first: the other workgroups wait for it
+            gran_store(xch + (step & 1) * H + k, (unsigned)(step + 1) ^ (step == 0 ? fault : 0u), h);      // first: the other workgroups wait for it
             tmp[d.hprev_off + row * H + k] = hprev;
             tmp[d.tc_off + row * H + k] = tc;
             float* g = tmp + d.gates_off + row * G;
@@ -577,11 +611,13 @@ __global__ __launch_bounds__(256) void lstm_multi_bwd_kernel(const LstmDesc* __r
     constexpr int H = LSTM_MH, G = 4 * H, HU = H / LSTM_NB, JQ = 16, JW = G / JQ;   // 16 j-chunks of 48 gate rows
     const int wg = blockIdx.x, tid = threadIdx.x;
     const int kk = tid & (HU - 1), jq = tid / HU;             // lane (jq, kk) sums W_hh[jq*48 + i][wg*16 + kk] dz[jq*48 + i]
-    __shared__ __attribute__((aligned(16))) float dz_s[G];
-    __shared__ float part_s[JQ][HU + 1];
+    MST_COOP_LDS(dz_s, G);
+    MST_COOP_LDS2(part_s, JQ, HU + 1);
     const float* whh = b.p[SP_PAR] + d.whh_off;
     const float* tmp = b.p[SP_TMP];
     float* gr = b.p[SP_GRAD];
+    int* status = reinterpret_cast<int*>(b.p[SP_WS] + d.status_off);
+    bool dead = false;
     lstm_gran_t* xch = reinterpret_cast<lstm_gran_t*>(b.p[SP_TMP] + d.xch_off) + 2 * H;     // [2][G], behind the forward's
     float w[JW];
 #pragma unroll
@@ -627,7 +663,7 @@ __global__ __launch_bounds__(256) void lstm_multi_bwd_kernel(const LstmDesc* __r
         }
         if (step == 0) break;
 #pragma unroll
-        for (int i = 0; i < G / 256; ++i) dz_s[tid + 256 * i] = gran_wait(xch + par * G + tid + 256 * i, epoch);
+        for (int i = 0; i < G / 256; ++i) dz_s[tid + 256 * i] = gran_wait(xch + par * G + tid + 256 * i, epoch, status, dead);
         __syncthreads();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -655,7 +691,19 @@ __global__ __launch_bounds__(256) void lstm_multi_clear_kernel(const LstmDesc* _
     const int n = 2 * (2 * d.H + 8 * d.H);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = 0.f;
 }
+
+// workgroups of the multi-workgroup kernels one CU holds at once, as the runtime reports it for THIS build of them (the
+// smaller of the two kernels' answers); the plan sizes co-resident launches from it
+int lstm_multi_blocks_per_cu() {
+#ifdef HIPSIM
+    return 4;
+#else
+    int f = 0, w = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, lstm_multi_fwd_kernel, 256, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, lstm_multi_bwd_kernel, 256, 0) != hipSuccess) return 0;
+    return f < w ? f : w;
 #endif
+}
 
 // W_hh (4H x H) -> W_hh^T (H x 4H) so that the H > 64 forward reads it lane-contiguously
 __global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __restrict__ descs, Bases b) {
@@ -672,12 +720,10 @@ __global__ __launch_bounds__(256) void lstm_transpose_kernel(const LstmDesc* __r
 
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0 || maxH <= 64) return 0;
-#ifndef HIPSIM
     if (multi) {       // the multi-workgroup flavour needs no transposed copy; its exchange tags restart from zero
         hipLaunchKernelGGL(lstm_multi_clear_kernel, dim3(4, count), dim3(256), 0, s, dev_descs, b);
         return (int)hipGetLastError();
     }
-#endif
     int nb = (4 * maxH * maxH + 255) / 256;
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(lstm_transpose_kernel, dim3(nb, count), dim3(256), 0, s, dev_descs, b);
@@ -698,12 +744,10 @@ static bool lstm_grouped(int count, int maxB) { return maxB >= 2 * LSTM_NS && (i
 
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-#ifndef HIPSIM
     if (multi) {
-        hipLaunchKernelGGL(lstm_multi_fwd_kernel, dim3(LSTM_NB, count), dim3(256), 0, s, dev_descs, b);
+        MST_LAUNCH_CORESIDENT(lstm_multi_fwd_kernel, dim3(LSTM_NB, count), dim3(256), s, dev_descs, b);
         return (int)hipGetLastError();
     }
-#endif
     if (maxH <= 64 && lstm_grouped(count, maxB))
         hipLaunchKernelGGL(lstm_fwd_group_kernel, dim3((maxB + LSTM_NS - 1) / LSTM_NS, count), dim3(256), 0, s, dev_descs, b);
     else if (maxH <= 64)
@@ -715,12 +759,10 @@ int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, in
 
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s) {
     if (count <= 0) return 0;
-#ifndef HIPSIM
     if (multi) {
-        hipLaunchKernelGGL(lstm_multi_bwd_kernel, dim3(LSTM_NB, count), dim3(256), 0, s, dev_descs, b);
+        MST_LAUNCH_CORESIDENT(lstm_multi_bwd_kernel, dim3(LSTM_NB, count), dim3(256), s, dev_descs, b);
         return (int)hipGetLastError();
     }
-#endif
     if (maxH <= 64 && lstm_grouped(count, maxB))
         hipLaunchKernelGGL(lstm_bwd_group_kernel, dim3((maxB + LSTM_NS - 1) / LSTM_NS, count), dim3(256), 0, s, dev_descs, b);
     else if (maxH <= 64)

@@ -149,8 +149,9 @@ struct LstmDesc {
     int64_t whht_off;    // [SP_TMP] W_hh transposed (H x 4H), built per forward when H > 64
     // multi-workgroup flavour (one-clip plans, H = 192, batch 1): the gate rows are split over LSTM_NB workgroups that exchange
     // h_t (forward) / dz_t (backward) through tagged 8-byte granules
-    int32_t multi;
+    int32_t multi;       // 0 single-workgroup flavours, 1 multi-workgroup, 2 multi-workgroup with an injected exchange fault (tests)
     int64_t xch_off;     // [SP_TMP] forward 2 x H granules, then backward 2 x 4H granules (8 bytes each)
+    int64_t status_off;  // [SP_WS, clip 0] the plan's device status word (int32): MST_DEV_* bits, sticky until the host clears it
 };
 #define LSTM_NB 12       // workgroups per sequence in the multi-workgroup flavour: 16 hidden units (64 gate rows) each at H = 192
 #define LSTM_MH 192
@@ -220,7 +221,8 @@ int launch_combine_phase(const CombineDesc* dev, int nblk, int which, Bases b, h
 // (reps = clips of a batched plan: clip r's slabs sit rep_stride floats after clip r-1's; summed clip-major, in order)
 // width > 0: the entry is a (count / width) x width block of a wider parameter matrix: element i lands at
 // dst + (i / width) * dst_ld + i % width (column blocks of a Linear whose input is a broadcast-concat, plan.hip linear_part)
-struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; int32_t width, dst_ld; int32_t single; /* 1: one slab for all clips (folded GEMM) */ };
+struct SlabEntry { int64_t dst, src, stride; int32_t count, splits; int32_t reps; int64_t rep_stride; int32_t width, dst_ld; int32_t single; /* 1: one slab for all clips (folded GEMM) */
+                   int64_t base; /* width > 0: offset of element (0, 0) of the parameter matrix the block belongs to (host-side disjointness check) */ };
 struct SlabBlock { int32_t entry, start; };   // one workgroup's 64-element slice of an entry
 
 // ---- derived layer sizes (style/model.py:31-33 and every ctor)
@@ -256,6 +258,7 @@ int launch_segred(const SegRedDesc* dev_descs, int members, int blocks_per_clip,
 int launch_lstm_transpose(const LstmDesc* dev_descs, int count, int maxH, int multi, Bases b, hipStream_t s);
 int launch_lstm_fwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s);
 int launch_lstm_bwd(const LstmDesc* dev_descs, int count, int maxB, int maxH, int multi, Bases b, hipStream_t s);
+int lstm_multi_blocks_per_cu();      // workgroups of the multi-workgroup LSTM kernels one CU holds at once (occupancy API)
 int launch_combine_fwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 int launch_combine_bwd(const CombineDesc* dev_descs, int count, int max_nblk, int all_small, Bases b, hipStream_t s);
 // `count` descriptors of identical shape (the clips of a batched plan), blockIdx.y = descriptor

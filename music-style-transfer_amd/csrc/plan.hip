@@ -253,13 +253,24 @@ struct mst_plan {
     struct Phase { int what; int pass; int begin, end; int xchg; };        // what: 0 schedule steps, 1 loss partials, 2 loss tail + seed
     std::vector<Phase> phases;
     int K() const { return d.clips > 1 ? d.clips : 1; }
-#ifndef HIPSIM
     static int device_cus() {          // compute units of the current device (256 on MI355X in SPX mode)
+#ifdef HIPSIM
+        return 16;                     // the interpreter co-schedules at most 48 blocks (hipsim::COOP_MAXB): 3 slots x 16
+#else
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         return cus;
-    }
 #endif
+    }
+    // Workgroups of ONE launch of the multi-workgroup LSTM kernels that are certainly resident together on this device: what the
+    // occupancy API reports per CU for these kernels minus one slot per CU, times the CUs.  The spare slot is the room for
+    // whatever else is running (a second stream's kernel, an RCCL kernel, the tail of the previous launch); a launch that needs
+    // more takes the single-workgroup flavour.  On a whole MI355X: (4 - 1) x 256 = 768 workgroups = 64 clips.
+    static int coresident_slots() {
+        const int per_cu = lstm_multi_blocks_per_cu();
+        return per_cu > 1 ? (per_cu - 1) * device_cus() : 0;
+    }
+    int64_t status_off = 0;            // [SP_WS, clip 0] device status word ("device_status")
     int64_t ext0_stride() const { return (int64_t)P() * NF * NPN * NPF; }
     int64_t ext1_stride() const { return (int64_t)Q() * NF * NUN * NUF; }
     // offset of clip k's slice of `space` relative to clip 0's
@@ -526,13 +537,13 @@ struct mst_plan {
             l.gates_off = tmp(n * 4 * H); l.c_off = tmp(n * H); l.hprev_off = tmp(n * H); l.tc_off = tmp(n * H);
             l.gout_off = sp.out.off + sp.coloff; l.gzx_off = zxs[i].off;
             l.whht_off = H > 64 ? tmp((int64_t)4 * H * H) : 0;
-#ifndef HIPSIM      // the interpreter runs workgroups one after another: a kernel whose workgroups wait for each other cannot run there
             // the LSTM_NB workgroups of a sequence wait for each other, so every workgroup of the launch must be resident at once:
-            // one group per clip, at most 3 workgroups per CU (the kernels fit 4) — up to 64 clips per launch on 256 CUs
-            // (3 workgroups per CU of the device the plan is created on: 768 on a whole MI355X, fewer on a partition)
-            l.multi = (LSTM_NB * K() <= 3 * device_cus() && H == LSTM_MH && sp.B == 1 && specs.size() == 1) ? 1 : 0;
-#endif
+            // one group per clip, as many as coresident_slots() allows on the device the plan is created on (a partition has fewer
+            // CUs); mst_plan_options.lstm_flavour = 1 always takes one workgroup per sequence
+            if (opt.lstm_flavour != 1 && H == LSTM_MH && sp.B == 1 && specs.size() == 1 && LSTM_NB * K() <= coresident_slots())
+                l.multi = opt.lstm_flavour == 2 ? 2 : 1;
             l.xch_off = l.multi ? tmp(2 * (2 * H + 2 * 4 * H)) : 0;
+            l.status_off = status_off;
             lstms.push_back(l);
             if (sp.B > maxB) maxB = sp.B;
             if (H > maxH) maxH = H;
@@ -627,7 +638,7 @@ struct mst_plan {
             w.out.kind = OUT_SLAB; w.out.space = SP_TMP; w.out.off = slab; w.out.slab_stride = stride; w.out.wcols = kb; w.out.bias_space = -1;
             op.bwd.push_back(Step{fd ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(w.M, w.N), w.ksplit});
             gemms.push_back(w);
-            SlabEntry e{woff, slab, stride, N * kb, w.ksplit}; e.width = kb; e.dst_ld = Kfull; e.single = fd ? 1 : 0;
+            SlabEntry e{woff, slab, stride, N * kb, w.ksplit}; e.width = kb; e.dst_ld = Kfull; e.single = fd ? 1 : 0; e.base = pt.off(wname);
             slabs[stage_idx(stage)].push_back(e);
             if (pbias) { SlabEntry eb{pt.off(bname), slab + (int64_t)N * kb, stride, N, w.ksplit}; eb.single = fd ? 1 : 0; slabs[stage_idx(stage)].push_back(eb); }
         }
@@ -811,6 +822,7 @@ void mst_plan::build() {
     // ---- inputs / targets (never zeroed, written by the host side)
     T instr = newT(C, z.I, "instr"), mode = newT(1, 2, "mode"), bpm = newT(1, 1, "bpm");
     newT(1, z.NI, "used_instruments"); newT(1, 1, "bpm_target");
+    status_off = newT(1, 64, "device_status").off;       // int32 word 0: MST_DEV_* bits (activation arena: never part of a zero list)
     t_losses = newT(1, 64, "losses"); t_saved = newT(1, MST_LOSS_SAVED, "loss_saved"); t_gl = newT(1, 64, "grad_losses");
     loss_scratch = tmp(mst_loss_scratch_floats());
     auto seg0 = [&](const T& t) { return seg(t, 0, 0, 0, 0, true); };      // broadcast over every row
@@ -1327,6 +1339,8 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                 if (s.kind != s0.kind || (!across_stages && s.stage != s0.stage)) continue;
                 // LSTM launches come in a register-resident (H <= 64) and an L2 flavour
                 if (is_lstm && ((s.b > 64) != (s0.b > 64))) continue;
+                // ... and the multi-workgroup flavour is a kernel of its own (grid and hidden size fixed): never merged with another
+                if (is_lstm && j != i && (lstms[s.first].multi || lstms[s0.first].multi)) continue;
                 if (j != i && !mergeable) continue;
                 done[j] = 1;
                 for (int q = 0; q < s.count; ++q) members.push_back(s.first + q);
@@ -1516,6 +1530,17 @@ void mst_plan::schedule() {
     split(1);
 }
 
+// two column blocks of one row-major matrix (row pitch ld), given by the offsets of their first elements from the matrix's
+// element (0, 0): do they share no element?  (both start in row 0 or any row: only the column intervals matter)
+static bool slab_columns_disjoint(int64_t off_x, int width_x, int64_t off_y, int width_y, int ld) {
+    const int64_t cx = off_x % ld, cy = off_y % ld;
+    if (cx + width_x > ld || cy + width_y > ld) return false;       // a block that wraps a row is not a column block
+    return cx + width_x <= cy || cy + width_y <= cx;
+}
+extern "C" int32_t mst_debug_slab_columns_disjoint(int64_t off_x, int32_t width_x, int64_t off_y, int32_t width_y, int32_t ld) {
+    return slab_columns_disjoint(off_x, width_x, off_y, width_y, ld) ? 1 : 0;
+}
+
 template <class D>
 static int up(const std::vector<D>& v, D** dev) {
     *dev = nullptr;
@@ -1562,11 +1587,10 @@ int mst_plan::upload() {
                 for (size_t j = i + 1; j < slabs_all.size() && slabs_all_ok; ++j) {
                     const SlabEntry& x = slabs_all[i]; const SlabEntry& y = slabs_all[j];
                     if (spans[i].second <= spans[j].first || spans[j].second <= spans[i].first) continue;
-                    // overlapping bounding spans: disjoint only if both are blocks of the same row pitch with disjoint column ranges
-                    if (!(x.width > 0 && y.width > 0 && x.dst_ld == y.dst_ld)) { slabs_all_ok = false; break; }
-                    const int64_t cx = x.dst % x.dst_ld, cy = y.dst % y.dst_ld;      // column offsets modulo the pitch (same base matrix)
-                    const int64_t bx = x.dst - cx, by = y.dst - cy;
-                    if ((bx - by) % x.dst_ld != 0 || !(cx + x.width <= cy || cy + y.width <= cx)) slabs_all_ok = false;
+                    // overlapping bounding spans: disjoint only if both are column blocks of the SAME parameter matrix (same base,
+                    // same row pitch) with disjoint column ranges, columns counted from the matrix's own first element
+                    if (!(x.width > 0 && y.width > 0 && x.dst_ld == y.dst_ld && x.base == y.base)) { slabs_all_ok = false; break; }
+                    slabs_all_ok = slab_columns_disjoint(x.dst - x.base, x.width, y.dst - y.base, y.width, x.dst_ld);
                 }
         }
         for (size_t i = 0; i < slabs_all.size(); ++i)
@@ -1591,6 +1615,7 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && ((opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64) || opt->gemm_run < 0 || opt->gemm_run > 64)) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && (opt->lstm_flavour < 0 || opt->lstm_flavour > 2 || opt->reserved[0] || opt->reserved[1])) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && (opt->tile_rows < 0 || opt->tile_r0 < 0 || (opt->tile_rows > 0 && (opt->tile_r0 + opt->tile_rows > d->R || d->clips > 1)))) {
         *status = MST_ERR_ARG; return nullptr;
     }
@@ -1706,6 +1731,19 @@ extern "C" int32_t mst_forward(const mst_plan* p, int32_t mask, const float* par
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
     const Bases b = make_bases(p, params, nullptr, ws, pitched, unpitched);
     return run_pass(p, p->list(mask, 0), mask, b, (hipStream_t)stream);
+}
+
+extern "C" int32_t mst_plan_status(const mst_plan* p, float* ws, int32_t clear, int32_t* status, mst_stream stream) {
+    if (!p || !ws || !status) return MST_ERR_ARG;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MST_ERR_LAUNCH;
+    int32_t word = 0;
+    if (hipMemcpy(&word, ws + p->status_off, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) return MST_ERR_LAUNCH;
+    *status = word;
+    if (clear && word) {
+        const int32_t zero = 0;
+        if (hipMemcpy(ws + p->status_off, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return MST_ERR_LAUNCH;
+    }
+    return MST_OK;
 }
 
 extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, mst_stream stream) {
@@ -1935,7 +1973,7 @@ extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t b
         int32_t* o = info + 5 * idx++;
         o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count;
         if (s->kind == K_GEMM || s->kind == K_GEMM_FOLD) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
-        else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; }
+        else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; o[3] = l.multi; }
         else if (s->kind == K_GATHER) { const GatherDesc& g = p->s_gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
         else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->s_segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
         else if (s->kind == K_COMB_F || s->kind == K_COMB_B) { const CombineDesc& c = p->s_combines[s->first]; o[0] = c.Cn; o[1] = c.rows; o[2] = c.cols; o[3] = c.nblk; }

@@ -40,17 +40,32 @@ class Dims(C.Structure):
 
 class PlanOptions(C.Structure):
     _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('tile_r0', C.c_int32),
-                ('tile_rows', C.c_int32), ('reserved', C.c_int32 * 3)]
+                ('tile_rows', C.c_int32), ('lstm_flavour', C.c_int32), ('reserved', C.c_int32 * 2)]
+
+
+DEV_LSTM_TIMEOUT = 1        # mst_amd.h MST_DEV_LSTM_TIMEOUT
+
+
+def describe_status(word):
+    parts = []
+    if word & DEV_LSTM_TIMEOUT:
+        parts.append('a granule of the multi-workgroup LSTM exchange did not arrive within 0.2 s (MST_DEV_LSTM_TIMEOUT): the '
+                     'launch was not fully resident — something else occupied the GPU next to a batched plan; results since then '
+                     'are NaN.  Plan option lstm_flavour=1 (MST_LSTM_FLAVOUR=1) takes the single-workgroup kernels')
+    if word & ~DEV_LSTM_TIMEOUT:
+        parts.append(f'unknown status bits {word & ~DEV_LSTM_TIMEOUT:#x}')
+    return '; '.join(parts)
 
 
 def options_from_env():
     """Developer switches of the Python binding; the C library itself reads no environment.
-    MST_GEMM=mfma|valu forces the 64x64 / 32x32 GEMM tiling, MST_NO_MERGE=1 gives one launch per scheduled member."""
+    MST_GEMM=mfma|valu forces the 64x64 / 32x32 GEMM tiling, MST_NO_MERGE=1 gives one launch per scheduled member,
+    MST_LSTM_FLAVOUR=1 keeps the H = 192 LSTM on one workgroup per sequence (mst_plan_options.lstm_flavour)."""
     ge = os.environ.get('MST_GEMM')
     if ge not in (None, '', 'mfma', 'valu'):
         raise MstError(f'MST_GEMM={ge!r}: expected mfma or valu')
     return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))),
-                gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')))
+                gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')), lstm_flavour=int(os.environ.get('MST_LSTM_FLAVOUR', '0')))
 
 
 _P = C.c_void_p
@@ -68,6 +83,8 @@ _SIGS = {
     'mst_plan_tensor': (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mst_plan_launch_count': (C.c_int32, [_P, C.c_int32, C.c_int32]),
     'mst_plan_layout': (C.c_int32, [_P, C.POINTER(C.c_int64 * 4)]),
+    'mst_plan_status': (C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
+    'mst_debug_slab_columns_disjoint': (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
     'mst_forward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     'mst_backward': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     'mst_zero_grads': (C.c_int32, [_P, C.c_int32, _P, _P]),
@@ -163,12 +180,13 @@ class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
     WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0, lstm_flavour=None):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
         env = options_from_env()
         opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
                            no_merge=env['no_merge'] if no_merge is None else int(no_merge),
-                           gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run), tile_r0=int(tile_r0), tile_rows=int(tile_rows))
+                           gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run), tile_r0=int(tile_r0), tile_rows=int(tile_rows),
+                           lstm_flavour=env['lstm_flavour'] if lstm_flavour is None else int(lstm_flavour))
         st = C.c_int32()
         self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:
@@ -177,6 +195,7 @@ class Plan:
         n = self.lib.mst_plan_workspace_floats(self.handle)
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._free_ws = []
+        self._touched = {}        # workspaces launched on since the last health check (check_touched)
         self._slots = {}
         lay = (C.c_int64 * 4)()
         check(self.lib.mst_plan_layout(self.handle, C.byref(lay)), 'mst_plan_layout')
@@ -229,15 +248,38 @@ class Plan:
             if t is not None:
                 self.view(name, ws=ws, clip=clip).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(-1), non_blocking=True)
 
+    def status(self, ws=None, clear=True):
+        """Device status word of a workspace (0 = healthy; MST_DEV_* bits otherwise).  Synchronises the current stream."""
+        word = C.c_int32()
+        check(self.lib.mst_plan_status(self.handle, ptr(self.ws if ws is None else ws), int(bool(clear)), C.byref(word),
+                                       current_stream(self.device)), 'mst_plan_status')
+        return word.value
+
+    def check_status(self, ws=None):
+        word = self.status(ws)
+        if word:
+            raise MstError('device status: ' + describe_status(word))
+
+    def _touch(self, ws):
+        ws = self.ws if ws is None else ws
+        self._touched[id(ws)] = ws
+        return ws
+
+    def check_touched(self):
+        """check_status of every workspace a launch went to since the last call."""
+        touched, self._touched = self._touched, {}
+        for ws in touched.values():
+            self.check_status(ws)
+
     def launch_count(self, mask=STAGE_ALL, backward=False):
         return self.lib.mst_plan_launch_count(self.handle, mask, int(backward))
 
     def forward(self, mask, params, pitched, unpitched, ws=None):
-        check(self.lib.mst_forward(self.handle, mask, ptr(params), ptr(self.ws if ws is None else ws), ptr(pitched),
+        check(self.lib.mst_forward(self.handle, mask, ptr(params), ptr(self._touch(ws)), ptr(pitched),
                                    ptr(unpitched), current_stream(self.device)), 'mst_forward')
 
     def backward(self, mask, params, gparams, pitched, unpitched, ws=None):
-        check(self.lib.mst_backward(self.handle, mask, ptr(params), ptr(gparams), ptr(self.ws if ws is None else ws),
+        check(self.lib.mst_backward(self.handle, mask, ptr(params), ptr(gparams), ptr(self._touch(ws)),
                                     ptr(pitched), ptr(unpitched), current_stream(self.device)), 'mst_backward')
 
     def zero_grads(self, mask, ws=None):
@@ -273,6 +315,7 @@ class Plan:
             import torch.distributed as dist
             all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
         xoff, xlen = C.c_int64(), C.c_int64()
+        self._touch(None)
         for ph in range(self.lib.mst_tiled_phase_count(self.handle)):
             check(self.lib.mst_tiled_phase(self.handle, ph, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched), ptr(unpitched),
                                            ptr(losses), int(bool(is_root)), current_stream(self.device), C.byref(xoff), C.byref(xlen)),
@@ -281,7 +324,7 @@ class Plan:
                 all_reduce(self.ws[xoff.value:xoff.value + xlen.value])
 
     def train_iteration(self, params, gparams, pitched, unpitched, losses=None, ws=None):
-        check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self.ws if ws is None else ws),
+        check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self._touch(ws)),
                                            ptr(pitched), ptr(unpitched), ptr(losses), current_stream(self.device)),
               'mst_train_iteration')
 

@@ -391,6 +391,7 @@ class StyleTransferModel(nn.Module):
         plan.uses = getattr(plan, 'uses', 0) + 1
         if g is not None:
             st = plan.static
+            plan._touch(None)                        # a replay launches on the plan's own workspace
             st['pitched'].copy_(pitched)
             if unpitched is not None:
                 st['unpitched'].copy_(unpitched)
@@ -401,6 +402,13 @@ class StyleTransferModel(nn.Module):
         plan.train_iteration(self._flat, gflat, pitched, unpitched, losses)
         self._publish_grads()
         return losses
+
+    def check_device_status(self):
+        """Raise MstError if a kernel reported a device-side failure (include/mst_amd.h MST_DEV_*: the multi-workgroup LSTM's
+        exchange timing out) on any workspace used since the last check.  Synchronises; call it where the loop reads its
+        losses back anyway (style.train.LossLog.flush does)."""
+        for plan in list(_native.get()._plans.values()):
+            plan.check_touched()
 
     def forward(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
         ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), torch.is_grad_enabled(), mode, bpm, pitched_channels,

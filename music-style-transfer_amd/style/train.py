@@ -62,8 +62,9 @@ def drop_silent(input):
 class LossLog:
     """Packed loss tensors of the iterations since the last flush."""
 
-    def __init__(self, path, pbar, flush_every):
+    def __init__(self, path, pbar, flush_every, health=None):
         self.path, self.pbar, self.flush_every = path, pbar, flush_every
+        self.health = health          # callable raising on a device-side failure (StyleTransferModel.check_device_status)
         self.pending = []
 
     def add(self, iteration, packed):
@@ -75,6 +76,8 @@ class LossLog:
         if not self.pending:
             return
         values = torch.stack([p for _, p in self.pending]).cpu().numpy()          # the one D2H copy
+        if self.health is not None:
+            self.health()             # a kernel-reported failure names itself here, before the NaN assert below would
         rows = []
         for (iteration, _), v in zip(self.pending, values):
             leaf = dict(zip(_native.LOSS_KEYS, v.tolist()))
@@ -115,7 +118,7 @@ def train(model, inputs, n_iterations=5000, iter_size=2, training_info_path='tra
     optimizer = optimizer or FusedAdam(model, lr=.01, step_size=200, gamma=.9)
     optimizer.zero_grad()
     pbar = ProgressBar(n_iterations) if progress else None
-    log = LossLog(training_info_path, pbar, flush_every)
+    log = LossLog(training_info_path, pbar, flush_every, health=getattr(model, 'check_device_status', None))
     for iteration in range(n_iterations):
         input, max_n_bars = drop_silent(next(inputs))
         if input is None:

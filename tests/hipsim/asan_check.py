@@ -56,6 +56,7 @@ def run(C_, R, T, widths, unp, clips=1, gemm=None):
 run(2, 2, 1, (8, 6, 3, 12, 4, 6), True)
 run(2, 1, 2, (8, 6, 3, 12, 4, 6), False)
 run(1, 1, 1, (64, 128, 8, 256, 8, 32), True)
+run(1, 3, 1, (64, 128, 8, 256, 8, 32), False)                      # three bars: the 12-workgroup LSTM exchanges h_t / dz_t (co-resident launch)
 run(1, 2, 1, (8, 6, 3, 12, 4, 6), True, clips=3)                    # batched plan, 32x32 GEMM tiling
 run(2, 1, 1, (8, 6, 3, 12, 4, 6), True, clips=2, gemm='mfma')       # batched plan on the 64x64 GEMM tiling
 run(1, 1, 2, (64, 128, 8, 256, 8, 32), False, gemm='mfma')          # one clip, full widths, 64x64 tiling

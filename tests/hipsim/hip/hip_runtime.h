@@ -8,6 +8,10 @@
 // Model: blocks run one after another; the threads of a block are ucontext fibers that are
 // resumed round-robin and park at __syncthreads() / wave collectives (shuffles, MFMA) until
 // every live participant has arrived.  Wave = 64 lanes, as on gfx950.
+// Kernels whose workgroups wait for each other (the multi-workgroup LSTM's tagged-granule exchange) are launched with
+// launch_coop(): every block of the grid is alive at once, one State per block, the scheduler sweeps block after block and
+// a spinning lane yields (s_sleep).  Such kernels declare their LDS through MST_COOP_LDS* (one copy per block) because
+// `__shared__` is a function-level static here.
 #pragma once
 #include <ucontext.h>
 
@@ -86,8 +90,10 @@ struct State {
     int wave_alive[16]; int wave_arrived[16]; unsigned wave_gen[16];
     float slot_f[16][WAVE][4];
     long progress = 0;
+    dim3 bidx;                  // launch_coop: the block this State runs
 };
-inline State& st() { static State s; return s; }
+inline State*& coop_cur() { static State* p = nullptr; return p; }      // launch_coop: the State of the block being swept
+inline State& st() { static State s; return coop_cur() ? *coop_cur() : s; }
 
 }  // namespace hipsim
 
@@ -128,7 +134,11 @@ inline void fiber_entry() {
     abort();
 }
 
-inline void yield() { switch_to_sched(); threadIdx = st().fibers[st().cur].tid; }
+inline void yield() {
+    switch_to_sched();
+    threadIdx = st().fibers[st().cur].tid;
+    if (coop_cur()) blockIdx = st().bidx;
+}
 
 inline void block_barrier() {
     State& s = st();
@@ -149,8 +159,7 @@ inline void wave_barrier() {
     while (s.wave_gen[w] == g) yield();
 }
 
-inline void run_block(const std::function<void()>& body) {
-    State& s = st();
+inline void init_block(State& s, const std::function<void()>& body) {
     int n = blockDim.x * blockDim.y * blockDim.z;
     if (n > 1024 || n <= 0) { fprintf(stderr, "hipsim: bad block size %d\n", n); abort(); }
     if ((int)s.fibers.size() < n) s.fibers.resize(1024);
@@ -172,22 +181,32 @@ inline void run_block(const std::function<void()>& body) {
         f.done = false;
         f.tid = dim3(i % blockDim.x, (i / blockDim.x) % blockDim.y, i / (blockDim.x * blockDim.y));
     }
+}
+
+// one round-robin pass over the live fibers of a block
+inline void sweep_block(State& s) {
+    for (int i = 0; i < s.nthreads; ++i) {
+        Fiber& f = s.fibers[i];
+        if (f.done) continue;
+        s.cur = i;
+        threadIdx = f.tid;
+#ifdef HIPSIM_ASAN
+        void* fake = nullptr;
+        __sanitizer_start_switch_fiber(&fake, f.stack, STACK);
+#endif
+        swapcontext(&s.sched, &f.ctx);
+#ifdef HIPSIM_ASAN
+        __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+    }
+}
+
+inline void run_block(const std::function<void()>& body) {
+    State& s = st();
+    init_block(s, body);
     while (s.alive > 0) {
         long before = s.progress;
-        for (int i = 0; i < n; ++i) {
-            Fiber& f = s.fibers[i];
-            if (f.done) continue;
-            s.cur = i;
-            threadIdx = f.tid;
-#ifdef HIPSIM_ASAN
-            void* fake = nullptr;
-            __sanitizer_start_switch_fiber(&fake, f.stack, STACK);
-#endif
-            swapcontext(&s.sched, &f.ctx);
-#ifdef HIPSIM_ASAN
-            __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
-#endif
-        }
+        sweep_block(s);
         if (s.progress == before) {
             fprintf(stderr, "hipsim: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n",
                     blockIdx.x, blockIdx.y, blockIdx.z);
@@ -207,6 +226,52 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... ar
                 blockIdx = dim3(x, y, z);
                 run_block(body);
             }
+}
+
+// Co-resident launch: all blocks alive at once.  A lane that polls another block's data yields through spin_yield(); the
+// launch is declared dead only when no fiber of any block has made progress for very many sweeps (a polling loop with a
+// bound of its own ends long before that).
+constexpr int COOP_MAXB = 48;
+inline int coop_block() { return (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); }
+inline void spin_yield() { yield(); }
+
+template <class K, class... A>
+inline void launch_coop(K kernel, dim3 grid, dim3 block, hipStream_t, A... args) {
+    gridDim = grid;
+    blockDim = block;
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    if (nb > COOP_MAXB) { fprintf(stderr, "hipsim: co-resident launch of %d blocks (max %d)\n", nb, COOP_MAXB); abort(); }
+    std::function<void()> body = [=]() { kernel(args...); };
+    std::vector<State*> blocks;
+    for (int i = 0; i < nb; ++i) {
+        State* s = new State();
+        s->bidx = dim3(i % grid.x, (i / grid.x) % grid.y, i / (grid.x * grid.y));
+        blockIdx = s->bidx;
+        init_block(*s, body);
+        blocks.push_back(s);
+    }
+    long idle = 0;
+    for (;;) {
+        int alive = 0;
+        long before = 0, after = 0;
+        for (State* s : blocks) before += s->progress;
+        for (State* s : blocks) {
+            if (s->alive <= 0) continue;
+            coop_cur() = s;
+            blockIdx = s->bidx;
+            sweep_block(*s);
+            alive += s->alive > 0;
+        }
+        coop_cur() = nullptr;
+        if (!alive) break;
+        for (State* s : blocks) after += s->progress;
+        idle = after == before ? idle + 1 : 0;
+        if (idle > (1 << 16)) { fprintf(stderr, "hipsim: co-resident launch made no progress\n"); abort(); }
+    }
+    for (State* s : blocks) {
+        for (Fiber& f : s->fibers) free(f.stack);
+        delete s;
+    }
 }
 
 template <class T>
@@ -237,6 +302,18 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; ret
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline float __fdividef(float a, float b) { return a / b; }
+// agent-scope atomics, bit casts, sleep and the wall clock of the multi-workgroup LSTM's granule exchange: fibers never
+// pre-empt each other, so plain accesses are atomic; s_sleep is where a polling lane lets the other blocks run; the clock
+// is a call counter (the kernels' time bound becomes a bound on polls)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_fetch_or(p, v, order, scope) hipsim_fetch_or((p), (v))
+static inline int hipsim_fetch_or(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline void __builtin_amdgcn_s_sleep(int) { hipsim::spin_yield(); }
+static inline long long wall_clock64() { static long long t = 0; hipsim::st().progress++; return ++t; }
 static inline void __threadfence() {}
 
 // f32 MFMA (gfx950 v_mfma_f32_16x16x4_f32): bit-for-bit a k-ordered fmaf chain per the CDNA4

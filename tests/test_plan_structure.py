@@ -43,3 +43,15 @@ def test_rhythm_encoder_linear_never_sees_the_135_wide_concat():
     rows = C * R * T * 10
     assert not [m for m in fwd if m[2] == 135], 'a forward GEMM reduces over the 135-wide concat'
     assert [m for m in fwd if m[0] == rows and m[1] == 32 and m[2] == 16], 'the channels block GEMM (rows x 32 x 16) is missing'
+
+
+def test_single_launch_slab_reduce_guard_counts_columns_from_the_matrix_base():
+    # two column blocks of one (rows x 128) parameter matrix, offsets from the matrix's own element (0, 0) — the plan passes
+    # `dst - base`, so a base that is not a multiple of the pitch no longer shifts the columns (base % ld = 100,
+    # cols [0, 40) vs [30, 50) were judged disjoint when the ABSOLUTE offset was taken modulo the pitch)
+    f = sim_native().lib.mst_debug_slab_columns_disjoint
+    assert f(0, 40, 30, 20, 128) == 0            # [0, 40) and [30, 50) overlap
+    assert f(0, 30, 30, 20, 128) == 1            # [0, 30) and [30, 50) do not
+    assert f(0, 40, 128 + 30, 20, 128) == 0      # blocks starting in different rows: still the same columns
+    assert f(100, 40, 10, 20, 128) == 0          # a block that wraps a row is not a column block: never judged disjoint
+    assert f(88, 40, 0, 88, 128) == 1

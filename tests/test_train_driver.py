@@ -85,6 +85,41 @@ def test_drop_silent_and_loss_log(tmp_path):
     log.add(2, bad)
     with pytest.raises(AssertionError):
         log.flush()
+    # a device-side failure names itself at the flush, before the NaN assert gets to speak
+    def health():
+        raise _native.MstError('device status: ' + _native.describe_status(_native.DEV_LSTM_TIMEOUT))
+    sick = LossLog(path, None, flush_every=1, health=health)
+    with pytest.raises(_native.MstError, match='MST_DEV_LSTM_TIMEOUT'):
+        sick.add(3, bad)
+
+
+@pytest.mark.gpu
+def test_lstm_exchange_timeout_surfaces_through_the_model(monkeypatch):
+    """MST_LSTM_FLAVOUR=2 makes workgroup 0 of the 12-workgroup StyleEncoder LSTM publish its first step under a wrong epoch
+    (mst_plan_options.lstm_flavour = 2): every consumer runs into the 0.2 s timeout, ORs MST_DEV_LSTM_TIMEOUT into the plan's
+    device status word and the launch drains; StyleTransferModel.check_device_status (what LossLog.flush calls) raises."""
+    import time
+    from oracle.synth import synth_clip
+    from style import _native
+    from style.train import build_model
+    monkeypatch.setenv('MST_LSTM_FLAVOUR', '2')
+    model = build_model(seed=108)
+    clip = {k: (v.to('cuda:0') if torch.is_tensor(v) else v) for k, v in synth_clip(0, 2, 3, 2, True).items()}
+    args = (clip['mode'], clip['bpm'], clip['pitched'], clip['instruments_features'], clip['unpitched'], clip['used_instruments'],
+            clip['bpm_int'])
+    t0 = time.time()
+    packed = model.train_iteration(*args)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 20., 'the faulted launch must drain within its time bound, not hang'
+    assert torch.isnan(packed[0])
+    with pytest.raises(_native.MstError, match='MST_DEV_LSTM_TIMEOUT'):
+        model.check_device_status()
+    model.check_device_status()                      # read-and-cleared: healthy again as far as the status word goes
+    monkeypatch.setenv('MST_LSTM_FLAVOUR', '0')      # a new plan (the options are part of the cache key) on healthy kernels
+    model.zero_grad()
+    packed = model.train_iteration(*args)
+    model.check_device_status()
+    assert torch.isfinite(packed[0])
 
 
 @pytest.mark.gpu
