@@ -399,9 +399,10 @@ int loss_bwd_batched(const float* pp, const float* pt, int64_t np, const float* 
                      const float* it, int ni, const float* mlg, const float* mt, const float* bp, const float* bt,
                      const float* saved, const float* gl, float* gp, float* gu, float* gi, float* gm, float* gb, LossBatch lb,
                      hipStream_t s, float info_scale) {
-    if (!pp || !pt || !saved || !gl || !gp || !gi || !gm || !gb || np <= 0 || lb.clips < 1) return MST_ERR_ARG;
+    if (!pp || !pt || !saved || !gl || !gi || !gm || !gb || np <= 0 || lb.clips < 1) return MST_ERR_ARG;
     const int has_u = (up && ut && gu && nu > 0) ? 1 : 0;
-    const int nbp = blocks_for(np), nbu = has_u ? blocks_for(nu) : 0;
+    // gp == nullptr: the pitched tensor's gradient is not wanted here (the applier's backward kernel computes it on the fly)
+    const int nbp = gp ? blocks_for(np) : 0, nbu = has_u ? blocks_for(nu) : 0;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(nbp + nbu + 1, lb.clips), dim3(256), 0, s, pp, pt, np, nbp, up, ut,
                        has_u ? nu : (int64_t)0, nbu, il, it, ni, mlg, mt, bp, bt, saved, gl, gp, gu, gi, gm, gb, lb, info_scale);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;

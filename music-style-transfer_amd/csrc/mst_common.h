@@ -59,7 +59,10 @@
 // address spaces a descriptor offset can live in: activations, flat params, flat param grads,
 // the two borrowed note tensors, the gradient arena (mirrors SP_WS offsets), scratch
 enum { SP_WS = 0, SP_PAR = 1, SP_GPAR = 2, SP_EXT0 = 3, SP_EXT1 = 4, SP_GRAD = 5, SP_TMP = 6, SP_COUNT = 7 };
-struct Bases { float* p[SP_COUNT]; };
+// flags: MST_BF_LOSS_FUSED — this backward pass belongs to mst_train_iteration: the gradient of the pitched prediction is not in
+// its gradient slot; the applier's backward kernel derives it from (prediction, target, the loss tail's saved Jacobian) itself
+enum { MST_BF_LOSS_FUSED = 1 };
+struct Bases { float* p[SP_COUNT]; int32_t flags; };
 
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SIGOUT = 2, ACT_BPM = 3 };
 
@@ -187,6 +190,9 @@ struct NotesDesc {
     int64_t out_off;             // ME: melody (Q,F,56,W), the channels already combined; PSA: (P,F,56,5)
     int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;   // PSA: g_oct / g_deg = gradient of the PRE-activations z, (P*F, 240 | 210)
     int64_t slab_off; int32_t slab_stride; int32_t nblk;    // one slab row per workgroup
+    // PSA backward (psa_bwd2_kernel): per-workgroup partial sums over qf of dL/dz per channel = partial gradients of `it`
+    // [SP_GRAD] (nblk, C, 240) and (nblk, C, 210); the loss tail's saved Jacobian and upstream loss gradients [SP_WS]
+    int64_t itp_oct_off, itp_deg_off, loss_saved_off, loss_gl_off;
     // ME only: the channel combine (style/model.py:296,796-815) is fused in.  nwc waves per channel leave partial sums:
     int32_t nwc;                 // <= 64
     int64_t part_off;            // [SP_TMP] forward: C*nwc partial sums of squares; backward: C*nwc partial a_c, then nwc partial b
@@ -268,6 +274,7 @@ int launch_me_bwd_reduce(const NotesDesc* dev, const NotesDesc& host, int count,
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& host, int count, Bases b, hipStream_t s);
+int psa_bwd_waves(int C);     // waves per workgroup of the applier's backward kernel (one per channel pair)
 // per-clip strides of a batched loss evaluation (all 0 for the stand-alone single-clip entry points)
 struct LossBatch { int32_t clips; int64_t ws, grad, tmp, ext0, ext1; };
 // the two halves of loss_fwd_batched for tiled plans: partial sums, then (after the ranks' sums met) tail

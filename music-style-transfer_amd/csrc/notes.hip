@@ -427,118 +427,174 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
 
 // Backward of the applier's note tail.  Per row (channel c, qf) and note n = (o, dg):
 //   h[j] = leaky(lo[o][j] + ld[dg][j]) (30),  z[i] = b[i] + sum_j W[i][j] h[j] + sum_k W[i][30 + k] ml[qf][n][k],  y = act(z) (5).
-// Lane = hidden feature j, TWO rows per wave (lanes 0..29: channel 2 cp, lanes 32..61: channel 2 cp + 1), one wave per qf.
-// With the feature on the lane every reduction over notes is a per-lane register accumulation — no cross-lane sums, no
-// role phase, no workgroup barrier in the loop: the lane keeps lo[0..7][j], ld[0..6][j] and W[0..4][j] in registers, the
-// row's 56 x 5 output gradients dz are staged once in a wave-private LDS region and read back as wave-uniform (broadcast)
-// 16-byte reads, and for every note (o, dg compile-time constants of the unrolled loop)
+// ONE WORKGROUP PER qf, ONE WAVE PER CHANNEL PAIR (lanes 0..29: channel 2 w, lanes 32..61: channel 2 w + 1, lane = hidden feature
+// j), the workgroup walking its qf's in lockstep.  With the feature on the lane every reduction over notes is a per-lane register
+// accumulation: the lane keeps ld[0..6][j] and W[0..4][j] in registers, the pair's 2 x 56 x 5 output gradients dz sit in a
+// wave-private LDS region and come back as wave-uniform 16-byte reads, and for every note
 //   dh = sum_i dz[i] W[i][j];  dW[i][j] += dz[i] h;  g = dh leaky'(h);  d_lo[o][j] += g;  d_ld[dg][j] += g.
-// The melody-linear columns need only the CHANNEL SUM of dz (ml does not depend on the channel):
+// What the kernel no longer round-trips through HBM (round 2 wrote 18 MB per clip from here and three more kernels re-read it):
+//   * dL/dz per row (the (positions x 450) gradients of the octave / degree pre-activations) existed only to be summed: over the
+//     channels (= gradient of rt[qf]: summed across the workgroup's waves through LDS, written once per qf) and over qf
+//     (= gradient of it[c]: the wave keeps 15 running sums per lane for ITS channels across all its qf's and leaves one partial row
+//     per workgroup; a column sum over the workgroups finishes it).  The per-row tensors and their segment reduce are gone.
+//   * LOSS = true (the backward of mst_train_iteration): dL/dy is not read either — it is a function of the prediction, the
+//     target (the borrowed pitched input) and six scalars of the loss tail (loss_bwd_kernel's formula, same operations), so the
+//     elementwise loss backward over the pitched tensor and its 2.9 MB per clip of gradient never exist.
+//   * the rt / it rows are fetched once per qf / once per workgroup instead of once per row.
+// The melody-linear columns need only the CHANNEL SUM of dz (ml does not depend on the channel): after the waves met,
 //   g_ml[qf][n][k] = sum_i dzsum[n][i] W[i][30 + k],  dW[i][30 + k] += dzsum[n][i] ml[qf][n][k],  db[i] += dzsum[n][i]
-// — a short second phase per qf with lane = (k, note group).  One slab row of weight gradients per wave.
-template <int ML>
-__global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+// with lane = (k, note group), the groups dealt over all waves.  Two workgroup barriers per qf; every sum has a fixed order.
+#ifndef PSA_BWD_MINW
+#define PSA_BWD_MINW 2
+#endif
+template <int ML, int NPB, bool LOSS>
+__global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
-    constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW;
+    constexpr int NLO = NOCT * PSA_HW, NLD = NDEG * PSA_HW, NOD = NOCT + NDEG;
     constexpr int ROWE = NPN * NPF;                       // 280 output elements per row
     constexpr int NSLOT = (2 * ROWE + 63) / 64;            // flat (row A | row B) elements per lane
-    constexpr int NG = 64 / ML;                            // note groups of the melody phase
-    constexpr int NT = (NPN + NG - 1) / NG;
-    __shared__ __attribute__((aligned(16))) float dz_s[4][2][NPN][8];      // [wave][row A|B][note][5 used of 8]
-    __shared__ __attribute__((aligned(16))) float dzs_s[4][2][NPN][8];     // channel sums, same layout
-    __shared__ float lo_s[4][NOCT][64];                                     // the row pair's octave rows, [octave][lane]
-    __shared__ float rto_s[4][NOCT + NDEG][64];                             // dL/dz summed over the channels of this qf (= g_rt)
-    __shared__ float red_s[4][NPF][64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NG = 64 / ML;                            // note groups per wave in the melody phase
+    constexpr int NPMIN = NPB == 1 ? 1 : NPB / 2 + 1;      // fewest waves a workgroup of this bucket has
+    constexpr int MAXN = (NPN + NPMIN * NG - 1) / (NPMIN * NG);      // notes per melody-phase lane, at most
+    __shared__ __attribute__((aligned(16))) float raw_s[NPB][2][2 * ROWE];      // [wave][y | t or dy][row A | row B], flat; later the wave's dL/dz
+    __shared__ __attribute__((aligned(16))) float dz_s[NPB][2][NPN][8];         // [wave][row A | B][note][5 used of 8]
+    __shared__ float lo_s[NPB][NOCT][64];                                       // the pair's octave rows, [octave][lane]
+    __shared__ __attribute__((aligned(16))) float dzs_s[NPN][8];                // dz summed over the channels of this qf
+    __shared__ float coef_s[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NP = blockDim.x >> 6, nthreads = blockDim.x;
     const int half = lane >> 5, jl = lane & 31;
     const bool jvalid = jl < PSA_HW;
     const int j = jvalid ? jl : PSA_HW - 1;
+    const int c = 2 * wv + half;
+    const bool rvalid = c < d.C;
+    const int cc = rvalid ? c : d.C - 1;
     const float* par = b.p[SP_PAR];
     const float* ws = b.p[SP_WS];
     float* gr = b.p[SP_GRAD];
+    const float* tgt = LOSS ? b.p[d.x_space] + d.x_off : gr + d.g_out_off;       // target rows (LOSS) or upstream gradient rows
     const int QF = d.Q * NF;
+    float (*rto)[64] = reinterpret_cast<float (*)[64]>(&raw_s[wv][0][0]);       // dL/dz of the wave's pair, [octave | degree][lane]
     float wj[NPF], dwj[NPF];                               // W[i][j] and its gradient
 #pragma unroll
     for (int i = 0; i < NPF; ++i) { wj[i] = par[d.wl_off + i * KL + j]; dwj[i] = 0.f; }
-    // melody phase: lane = (k, note group g3)
+    float itv[NOD], acc_it[NOD];                           // it[c] rows of this lane's channel; running sums of dL/dz over qf
+#pragma unroll
+    for (int q = 0; q < NOD; ++q) {
+        itv[q] = q < NOCT ? ws[d.it_oct_off + (int64_t)cc * NLO + q * PSA_HW + j] : ws[d.it_deg_off + (int64_t)cc * NLD + (q - NOCT) * PSA_HW + j];
+        acc_it[q] = 0.f;
+    }
+    // melody phase: lane = (k, note group g3); the NP * NG groups of the workgroup deal the 56 notes
     const int k = lane % ML, g3 = lane / ML;
     const bool mact = g3 < NG;
+    const int G = wv * NG + g3, NGT = NP * NG;
     float wm[NPF], dwm[NPF], dbm[NPF];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) { wm[i] = par[d.wl_off + i * KL + PSA_HW + k]; dwm[i] = 0.f; dbm[i] = 0.f; }
-    float* dzf = &dz_s[wv][0][0][0];                      // flat views: row A at [0, 448), row B at [448, 896) (8 floats per note)
-    float* dzsf = &dzs_s[wv][0][0][0];
-    // per-lane constants of the cooperative dz staging: flat element e = lane + 64 q of (row A | row B)
-    int e_lds[NSLOT], e_off[NSLOT];
-    bool e_dur[NSLOT], e_rowb[NSLOT], e_in[NSLOT];
+    if (LOSS) {
+        // d total / d (TP FP FN SEvel SEdur BCE) of the pitched tensor from the loss tail's saved Jacobian (loss_bwd_kernel)
+        if (tid < 8) {
+            const float* saved = ws + d.loss_saved_off;
+            const float* gl = ws + d.loss_gl_off;
+            float gk[MST_N_LOSSES], sk[MST_N_LOSSES];
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-        const int e = lane + 64 * q;
-        const int hb = e >= ROWE ? 1 : 0, ee = e - hb * ROWE;
-        const int nn = ee / NPF, ii = ee - nn * NPF;
-        e_in[q] = e < 2 * ROWE; e_rowb[q] = hb != 0; e_dur[q] = ii == 0;
-        e_off[q] = e_in[q] ? ee : 0;
-        e_lds[q] = hb * (NPN * 8) + nn * 8 + ii;
+            for (int q = 0; q < MST_N_LOSSES; ++q) { gk[q] = gl[q]; sk[q] = saved[q * 16 + tid]; }
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < MST_N_LOSSES; ++q) a += gk[q] != 0.f ? gk[q] * sk[q] : 0.f;
+            coef_s[tid] = a;
+        }
+        __syncthreads();
     }
-    // Everything a row pair reads from global memory, fetched ONE PAIR AHEAD of its use (two waves per SIMD cannot hide a
-    // dependent load behind another wave's work): degree rows, octave rows, predictions and their gradients.
-    // (octave / degree rows = leaky(rt[qf] + it[c]): the Linear over the broadcast-concat, decomposed — plan.hip)
-    struct PairIn { float ld[NDEG], lo[NOCT], y[NSLOT], dy[NSLOT]; };
-    auto fetch = [&](int qf, int c0, PairIn& r) {
-        const int c = c0 + half;
-        const int64_t cc_ = c < d.C ? c : d.C - 1;
+    const float cTP = LOSS ? coef_s[0] : 0.f, cFP = LOSS ? coef_s[1] : 0.f, cFN = LOSS ? coef_s[2] : 0.f;
+    const float cSEV = LOSS ? coef_s[3] : 0.f, cSED = LOSS ? coef_s[4] : 0.f, cBCE = LOSS ? coef_s[5] : 0.f;
+    // flat element e = lane + 64 q of the pair's (row A | row B): which row, offset inside the row (recomputed where used: nine
+    // index registers and their flags cost a wave per SIMD)
+    // what a qf needs from global memory — the rt rows, the pair's predictions and targets — fetched behind the PREVIOUS qf's
+    // note loop (its registers are free then), so the loads fly under that qf's reductions, barriers and melody phase
+    // Every global access below is `uniform base pointer (SGPR pair) [32-bit lane offset]`: with 64-bit per-lane addresses the
+    // compiler kept two address registers per outstanding load and spilled ~300 bytes per lane at three waves per SIMD.
+    typedef const MST_GLOBAL_AS float* gptr_t;
+    const gptr_t y0 = (gptr_t)(ws + d.out_off), t0 = (gptr_t)tgt;
+    const gptr_t rto0 = (gptr_t)(ws + d.rt_oct_off), rtd0 = (gptr_t)(ws + d.rt_deg_off), ml0 = (gptr_t)(ws + d.ml_off);
+    struct QfIn { float rt[NOD], y[NSLOT], t[NSLOT]; };
+    // flat element e = lane + 64 q of the pair's (row A | row B): q < 4 lies in row A, q > 4 in row B, q = 4 straddles
+    const unsigned rowA = (unsigned)((2 * wv < d.C ? 2 * wv : 0) * QF) * ROWE + lane;
+    const unsigned rowB = (unsigned)((2 * wv + 1 < d.C ? 2 * wv + 1 : 0) * QF) * ROWE + lane;
+    auto fetch = [&](int qf_, QfIn& r) {
+        const unsigned oo = (unsigned)qf_ * NLO + j, od = (unsigned)qf_ * NLD + j;
 #pragma unroll
-        for (int q = 0; q < NDEG; ++q)
-            r.ld[q] = lrelu(ws[d.rt_deg_off + (int64_t)qf * NLD + q * PSA_HW + j] + ws[d.it_deg_off + cc_ * NLD + q * PSA_HW + j]);
-#pragma unroll
-        for (int o = 0; o < NOCT; ++o)
-            r.lo[o] = lrelu(ws[d.rt_oct_off + (int64_t)qf * NLO + o * PSA_HW + j] + ws[d.it_oct_off + cc_ * NLO + o * PSA_HW + j]);
+        for (int q = 0; q < NOD; ++q) r.rt[q] = q < NOCT ? rto0[oo + q * PSA_HW] : rtd0[od + (q - NOCT) * PSA_HW];
+        const unsigned a = rowA + (unsigned)qf_ * ROWE, bb = rowB + (unsigned)qf_ * ROWE;
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
-            const int cc = c0 + (e_rowb[q] ? 1 : 0);
-            const int64_t pos = ((int64_t)(cc < d.C ? cc : 0) * QF + qf) * ROWE + e_off[q];
-            r.y[q] = ws[d.out_off + pos];
-            r.dy[q] = gr[d.g_out_off + pos];
+            const int e0 = 64 * q;                          // compile-time part of the element index
+            unsigned pos;
+            if (e0 + 63 < ROWE) pos = a + e0;
+            else if (e0 >= ROWE) pos = (e0 + 63 < 2 * ROWE || lane + e0 < 2 * ROWE) ? bb + (e0 - ROWE) : bb;
+            else pos = lane + e0 < ROWE ? a + e0 : bb + (e0 - ROWE);
+            r.y[q] = y0[pos];
+            r.t[q] = t0[pos];
         }
     };
-    const int stride = gridDim.x * 4;
-    int qf = blockIdx.x * 4 + wv, c0 = 0;
-    bool have = qf < QF;
-    PairIn cur;
-    if (have) fetch(qf, 0, cur);
-    float dzsum[NSLOT];
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) dzsum[q] = 0.f;
-#pragma unroll
-    for (int o = 0; o < NOCT + NDEG; ++o) rto_s[wv][o][lane] = 0.f;
-    while (have) {                                         // wave-uniform
-        int nqf = qf, nc0 = c0 + 2;
-        if (nc0 >= d.C) { nc0 = 0; nqf = qf + stride; }
+    int qf = blockIdx.x;
+    bool have = qf < QF;                                   // workgroup-uniform
+    QfIn cur;
+    if (have) fetch(qf, cur);
+    while (have) {
+        const int nqf = qf + gridDim.x;
         const bool nhave = nqf < QF;
-        PairIn nxt;
-        if (nhave) fetch(nqf, nc0, nxt);                   // in flight under this pair's arithmetic
-        const int c = c0 + half;
-        const bool rvalid = c < d.C;
-        const int64_t row = (int64_t)(rvalid ? c : d.C - 1) * QF + qf;
-        float dld[NDEG];
+        // ---- dz = dL/dy act'(y) of both rows (zeros for an absent row B): rows staged flat, then one lane per (row, note)
 #pragma unroll
-        for (int q = 0; q < NDEG; ++q) dld[q] = 0.f;
-        MST_WAVE_SYNC();                                   // the previous pair's LDS reads are done
-#pragma unroll
-        for (int o = 0; o < NOCT; ++o) lo_s[wv][o][lane] = cur.lo[o];
-        // dz = dy act'(y) of both rows (zeros for an absent row B)
-#pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
-            const bool ok = e_in[q] && (c0 + (e_rowb[q] ? 1 : 0)) < d.C;
-            const float y = cur.y[q];
-            const float dzv = ok ? cur.dy[q] * (e_dur[q] ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y)) : 0.f;
-            if (e_in[q]) dzf[e_lds[q]] = dzv;
-            dzsum[q] += dzv;
-        }
+        for (int q = 0; q < NSLOT; ++q)
+            if (lane + 64 * q < 2 * ROWE) { raw_s[wv][0][lane + 64 * q] = cur.y[q]; raw_s[wv][1][lane + 64 * q] = cur.t[q]; }
         MST_WAVE_SYNC();
-        const float* dzr = dzf + half * (NPN * 8);
-        float* glop = gr + d.g_oct_off + row * NLO + j;
+        float dzv[2][NPF];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = lane + 64 * u;
+            const bool act = it < 2 * NPN;
+            const int r = it >= NPN ? 1 : 0, n = act ? it - r * NPN : 0;
+            const float* yy = &raw_s[wv][0][r * ROWE + n * NPF];
+            const float* tt = &raw_s[wv][1][r * ROWE + n * NPF];
+            const bool rowok = act && (2 * wv + r) < d.C;
+            float y5[NPF], g5[NPF];
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) { y5[i] = yy[i]; g5[i] = tt[i]; }
+            if (LOSS) {                                    // g5 holds the target: same operations as loss_bwd_kernel
+                const float p0 = y5[0], pv = y5[1], t0 = g5[0], tv = g5[1];
+                const float m = tv > 0.f ? 1.f : 0.f;
+                float gv = cTP * (pv < tv ? 1.f : (pv == tv ? 0.5f : 0.f));
+                gv += cFP * (pv - tv > 0.f ? 1.f : 0.f) - cFN * (tv - pv > 0.f ? 1.f : 0.f);
+                gv -= cSEV * 2.f * (tv - pv) * m;
+                g5[0] = cSED * 2.f * (p0 - fminf(t0, 6.f)) * (1.f / 36.f) * m;
+                g5[1] = gv;
+#pragma unroll
+                for (int a = 2; a < NPF; ++a) g5[a] = cBCE * m * (y5[a] - g5[a]) / fmaxf((1.f - y5[a]) * y5[a], 1e-12f);
+            }
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const float y = y5[i];
+                dzv[u][i] = rowok ? g5[i] * (i == 0 ? y * (1.f - y * (1.f / 6.f)) : y * (1.f - y)) : 0.f;
+            }
+        }
+        // (the staged rows are dead from here on: their storage becomes the wave's dL/dz slots)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = lane + 64 * u;
+            if (it < 2 * NPN) {
+                const int r = it >= NPN ? 1 : 0, n = it - r * NPN;
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) dz_s[wv][r][n][i] = dzv[u][i];
+            }
+        }
+        float ldv[NDEG], dld[NDEG];
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) lo_s[wv][o][lane] = lrelu(cur.rt[o] + itv[o]);
+#pragma unroll
+        for (int q = 0; q < NDEG; ++q) { ldv[q] = lrelu(cur.rt[NOCT + q] + itv[NOCT + q]); dld[q] = 0.f; }
+        MST_WAVE_SYNC();
+        const float* dzr = &dz_s[wv][half][0][0];
         // the octave loop is a REAL loop (a fully unrolled 56-note body made hipcc hoist every independent add / select to
         // the top and spill 500 registers); the degree rows stay in registers, the octave rows come from LDS
 #pragma unroll 1
@@ -550,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
                 const float* zr = dzr + (o * NDEG + dg) * 8;
                 const float4 z4 = *reinterpret_cast<const float4*>(zr);
                 const float z5 = zr[4];
-                const float xh = lo + cur.ld[dg];
+                const float xh = lo + ldv[dg];
                 const float slope = xh > 0.f ? 1.f : LEAKY;
                 const float h = xh * slope;
                 float dh = z4.x * wj[0];
@@ -560,66 +616,81 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
                 const float g = dh * slope;
                 dlo += g; dld[dg] += g;
             }
-            // gradient of the PRE-activation (leaky' from the activation's sign); sole writer of this row
+            // gradient of the PRE-activation (leaky' from the activation's sign)
             const float dzo = rvalid ? dlo * dlrelu(lo) : 0.f;
-            if (jvalid && rvalid) glop[o * PSA_HW] = dzo;
-            rto_s[wv][o][lane] += dzo;                     // lane-private slot: summed over the channels of this qf
+            rto[o][lane] = dzo;
         }
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) acc_it[o] += rto[o][lane];                // (lane-private slots, static register indices)
+        float mlv[MAXN];                                   // this lane's melody-linear activations of the qf: needed after the barriers
+#pragma unroll
+        for (int u = 0; u < MAXN; ++u) {
+            const int n = G + u * NGT;
+            mlv[u] = ml0[((unsigned)qf * NPN + ((mact && n < NPN) ? n : 0)) * ML + k];
+        }
+        if (nhave) fetch(nqf, cur);                        // the next qf's operands: in flight from here to the top of the loop
 #pragma unroll
         for (int q = 0; q < NDEG; ++q) {
-            const float dzd = rvalid ? dld[q] * dlrelu(cur.ld[q]) : 0.f;
-            if (jvalid && rvalid) gr[d.g_deg_off + row * NLD + q * PSA_HW + j] = dzd;
-            rto_s[wv][NOCT + q][lane] += dzd;
+            const float dzd = rvalid ? dld[q] * dlrelu(ldv[q]) : 0.f;
+            rto[NOCT + q][lane] = dzd;
+            acc_it[NOCT + q] += dzd;
         }
-        if (nc0 == 0) {
-            // ---- last pair of this qf.  g_rt[qf] = sum over the channels of dL/dz (the two halves of the wave hold the even /
-            // odd channels): sole writer of this row of the rt gradients
-            MST_WAVE_SYNC();
-            if (half == 0 && jvalid) {
-#pragma unroll
-                for (int o = 0; o < NOCT; ++o) gr[d.rt_oct_off + (int64_t)qf * NLO + o * PSA_HW + j] = rto_s[wv][o][lane] + rto_s[wv][o][lane + 32];
-#pragma unroll
-                for (int q = 0; q < NDEG; ++q) gr[d.rt_deg_off + (int64_t)qf * NLD + q * PSA_HW + j] = rto_s[wv][NOCT + q][lane] + rto_s[wv][NOCT + q][lane + 32];
+        __syncthreads();                                   // every wave's dz and dL/dz of this qf are in LDS
+        // ---- g_rt[qf] = sum over the channels of dL/dz (waves in order, even channel before odd): sole writer of this row
+        for (int w = tid; w < NLO + NLD; w += nthreads) {
+            const int q = w / PSA_HW, jj = w - q * PSA_HW;
+            float a = 0.f;
+            for (int u = 0; u < NP; ++u) {
+                const float* ru = &raw_s[u][0][0] + q * 64 + jj;
+                a += ru[0] + ru[32];
             }
-            MST_WAVE_SYNC();
+            if (w < NLO) gr[d.rt_oct_off + (int64_t)qf * NLO + w] = a;
+            else gr[d.rt_deg_off + (int64_t)qf * NLD + (w - NLO)] = a;
+        }
+        for (int e = tid; e < ROWE; e += nthreads) {
+            const int n = e / NPF, i = e - n * NPF;
+            float a = 0.f;
+            for (int u = 0; u < NP; ++u) a += dz_s[u][0][n][i] + dz_s[u][1][n][i];
+            dzs_s[n][i] = a;
+        }
+        __syncthreads();
+        // ---- the melody-linear columns from the channel sums
+        if (mact) {
 #pragma unroll
-            for (int o = 0; o < NOCT + NDEG; ++o) rto_s[wv][o][lane] = 0.f;
-            // ---- the melody-linear columns from the channel sums
-            MST_WAVE_SYNC();
-#pragma unroll
-            for (int q = 0; q < NSLOT; ++q) {
-                if (e_in[q]) dzsf[e_lds[q]] = dzsum[q];
-                dzsum[q] = 0.f;
-            }
-            MST_WAVE_SYNC();
-#pragma unroll 2
-            for (int tt = 0; tt < NT; ++tt) {
-                const int n = g3 + tt * NG;
-                const bool ok = mact && n < NPN;
-                const int nn = ok ? n : 0;
-                float s5[NPF];
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) s5[i] = dzsf[nn * 8 + i] + dzsf[NPN * 8 + nn * 8 + i];
-                const int64_t mi = ((int64_t)qf * NPN + nn) * ML + k;
-                const float mlv = ws[d.ml_off + mi];
-                float gm = s5[0] * wm[0];
-#pragma unroll
-                for (int i = 1; i < NPF; ++i) gm = fmaf(s5[i], wm[i], gm);
-                if (ok) {
-                    gr[d.g_ml_off + mi] = gm;              // sole writer (all channels already summed)
-#pragma unroll
-                    for (int i = 0; i < NPF; ++i) { dwm[i] = fmaf(s5[i], mlv, dwm[i]); dbm[i] += s5[i]; }
+            for (int u = 0; u < MAXN; ++u) {
+                const int n = G + u * NGT;
+                if (n < NPN) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(&dzs_s[n][0]);
+                    const float s5 = dzs_s[n][4];
+                    float gm = s4.x * wm[0];
+                    gm = fmaf(s4.y, wm[1], gm); gm = fmaf(s4.z, wm[2], gm); gm = fmaf(s4.w, wm[3], gm); gm = fmaf(s5, wm[4], gm);
+                    gr[d.g_ml_off + ((int64_t)qf * NPN + n) * ML + k] = gm;      // sole writer (all channels already summed)
+                    const float mv = mlv[u];
+                    dwm[0] = fmaf(s4.x, mv, dwm[0]); dwm[1] = fmaf(s4.y, mv, dwm[1]); dwm[2] = fmaf(s4.z, mv, dwm[2]);
+                    dwm[3] = fmaf(s4.w, mv, dwm[3]); dwm[4] = fmaf(s5, mv, dwm[4]);
+                    dbm[0] += s4.x; dbm[1] += s4.y; dbm[2] += s4.z; dbm[3] += s4.w; dbm[4] += s5;
                 }
             }
         }
-        cur = nxt; qf = nqf; c0 = nc0; have = nhave;
+        qf = nqf; have = nhave;
+        // (no barrier here: the next qf's wave-private writes follow its readers by the two barriers above; dzs_s is rewritten
+        // only behind the next qf's first barrier)
+    }
+    // ---- gradient of it[c]: this workgroup's partial sums over its qf's, one row per workgroup (a column sum finishes them)
+    if (rvalid && jvalid) {
+        float* po = gr + d.itp_oct_off + ((int64_t)blockIdx.x * d.C + c) * NLO + j;
+        float* pd = gr + d.itp_deg_off + ((int64_t)blockIdx.x * d.C + c) * NLD + j;
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) po[o * PSA_HW] = acc_it[o];
+#pragma unroll
+        for (int q = 0; q < NDEG; ++q) pd[q * PSA_HW] = acc_it[NOCT + q];
     }
     // ---- one slab row per workgroup: linear.weight (5 x KL) then linear.bias (5); partial sums meet in a fixed order
     constexpr int NWT = NPF * KL + NPF;
-    static_assert(NWT <= 256 && 4 * NWT <= 4 * 2 * NPN * 8, "slab row wider than the workgroup / the staging it reuses");
-    float* wsum = &dz_s[0][0][0][0] + wv * NWT;           // dz staging is free now
-    float (*red)[64] = red_s[wv];
-    __syncthreads();
+    static_assert(NWT <= 2 * NPN * 8 && NPF * 64 <= 4 * ROWE, "slab row wider than the staging it reuses");
+    __syncthreads();                                       // all LDS staging is free now
+    float* wsum = &dz_s[wv][0][0][0];                      // NWT floats per wave
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(&raw_s[wv][0][0]);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) red[i][lane] = dwj[i];
     MST_WAVE_SYNC();
@@ -651,9 +722,11 @@ __global__ __launch_bounds__(256, 2) void psa_notes_bwd_kernel(const NotesDesc* 
         wsum[NPF * KL + lane] = a;
     }
     __syncthreads();
-    const float* w0 = &dz_s[0][0][0][0];
-    if (tid < NWT)
-        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + tid] = (w0[tid] + w0[NWT + tid]) + (w0[2 * NWT + tid] + w0[3 * NWT + tid]);
+    for (int w = tid; w < NWT; w += nthreads) {
+        float a = 0.f;
+        for (int u = 0; u < NP; ++u) a += (&dz_s[u][0][0][0])[w];
+        b.p[SP_TMP][d.slab_off + (int64_t)blockIdx.x * d.slab_stride + w] = a;
+    }
 }
 
 // ============================================================================ dispatch
@@ -697,8 +770,22 @@ int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
     PSA_DISPATCH(psa_notes_fwd_kernel, dim3(QF < 4096 ? QF : 4096, count), dim3(64));
     return (int)hipGetLastError();
 }
+int psa_bwd_waves(int C) { return (C + 1) / 2; }      // one wave per channel pair
+#define PSA_BWD_LAUNCH(ML_, NPB_)                                                                                               \
+    {                                                                                                                           \
+        if (b.flags & MST_BF_LOSS_FUSED) hipLaunchKernelGGL((psa_bwd2_kernel<ML_, NPB_, true>), grid, dim3(64 * np), 0, s, dev, b);   \
+        else hipLaunchKernelGGL((psa_bwd2_kernel<ML_, NPB_, false>), grid, dim3(64 * np), 0, s, dev, b);                          \
+    }
+#define PSA_BWD_BUCKETS(ML_)                                                                        \
+    if (np <= 1) PSA_BWD_LAUNCH(ML_, 1) else if (np <= 2) PSA_BWD_LAUNCH(ML_, 2) else if (np <= 4) PSA_BWD_LAUNCH(ML_, 4)  \
+    else if (np <= 8) PSA_BWD_LAUNCH(ML_, 8) else PSA_BWD_LAUNCH(ML_, 16)
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
-    PSA_DISPATCH(psa_notes_bwd_kernel, dim3(h.nblk, count), dim3(256));
+    const int np = psa_bwd_waves(h.C);
+    if (np > 16) return MST_ERR_UNSUPPORTED;
+    const dim3 grid(h.nblk, count);
+    if (h.ML == 20) { PSA_BWD_BUCKETS(20) }
+    else if (h.ML == 14) { PSA_BWD_BUCKETS(14) }
+    else return MST_ERR_UNSUPPORTED;
     return (int)hipGetLastError();
 }
 

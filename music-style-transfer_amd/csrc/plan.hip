@@ -320,6 +320,7 @@ struct mst_plan {
         const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
         n.oct_off += a; n.deg_off += a; n.rt_oct_off += a; n.rt_deg_off += a; n.it_oct_off += a; n.it_deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
         n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += t; n.part_off += t; n.stats_off += t;
+        n.itp_oct_off += a; n.itp_deg_off += a; n.loss_saved_off += a; n.loss_gl_off += a;
         return n;
     }
 
@@ -1016,7 +1017,15 @@ void mst_plan::build() {
     // and the (positions x 88) concat are never written.  The backward note kernel leaves dL/dz per row; its column sums over c
     // and over qf are the gradients of rt and it.
     const int KA = z.PSA_SL + z.PSA_RL + z.PSA_IL, QF_ = Q_ * NF;
-    T rt_x[2], it_x[2], gz_x[2];
+    // backward note kernel: one workgroup per qf (a wave per channel pair) up to a cap sized to keep ~15 waves per CU busy over
+    // all clips; every workgroup leaves one row of weight-gradient partials and one row of it-gradient partials
+    const int psa_np = psa_bwd_waves(C);
+    int psa_nblk;
+    {
+        const int cap = K() == 1 ? 320 : std::max(4, (256 * 15) / (K() * psa_np));
+        psa_nblk = std::min(QF_, cap);
+    }
+    T rt_x[2], it_x[2], itp_x[2];
     for (int which = 0; which < 2; ++which) {
         const std::string lin = m + (which ? ".scale_degree_linear" : ".octave_linear");
         const int Nw = NPF * 6 * (which ? NDEG : NOCT);
@@ -1025,8 +1034,12 @@ void mst_plan::build() {
         linear_part(AP, psa_sl, true, lin + ".weight", 0, KA, lin + ".bias", nullptr, Nw, sb, 0);
         linear_part(AP, psa_il, true, lin + ".weight", z.PSA_SL + z.PSA_RL, KA, "", &sb, Nw, it_x[which], 0);
         linear_part(AP, psa_rl, true, lin + ".weight", z.PSA_SL, KA, "", nullptr, Nw, rt_x[which], 0);
-        gz_x[which] = newT(P_ * NF, Nw);                   // only its gradient slot is used
-        bcast_add_bwd(AP, gz_x[which], C, QF_, rt_x[which], it_x[which], false);
+        // gradient of it[c] = sum over qf of dL/dz[c, qf]: the note kernel sums its own qf's, this sums the workgroups' rows
+        // (only the gradient slot of itp is used)
+        itp_x[which] = newT(psa_nblk, C * Nw);
+        Op op; op.stage = AP;
+        column_sum(op, itp_x[which].off, C * Nw, psa_nblk, C * Nw, it_x[which].off);
+        ops.push_back(op);
     }
     T ml = rowlin(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
@@ -1034,13 +1047,12 @@ void mst_plan::build() {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
         n.rt_oct_off = rt_x[0].off; n.rt_deg_off = rt_x[1].off; n.it_oct_off = it_x[0].off; n.it_deg_off = it_x[1].off; n.ml_off = ml.off;
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
-        n.out_off = xp.off; n.g_out_off = xp.off; n.g_oct_off = gz_x[0].off; n.g_deg_off = gz_x[1].off; n.g_ml_off = ml.off;
+        n.out_off = xp.off; n.g_out_off = xp.off; n.g_ml_off = ml.off;
+        n.itp_oct_off = itp_x[0].off; n.itp_deg_off = itp_x[1].off;
+        n.x_space = SP_EXT0; n.x_off = 0;                     // the target of the fused loss backward: the pitched input itself
+        n.loss_saved_off = t_saved.off; n.loss_gl_off = t_gl.off;
         const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
-        const int qf = Q_ * NF;
-        // forward: a workgroup per qf up to the cap.  backward: a wave per qf, four per workgroup, one slab row per wave
-        const int psa_blk = K() == 1 ? 512 : (4096 / K() < 8 ? 8 : (4096 / K() > 512 ? 512 : 4096 / K()));
-        const int want = (qf + 3) / 4;
-        n.nblk = want < psa_blk ? want : psa_blk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
+        n.nblk = psa_nblk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
@@ -1282,9 +1294,12 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             if (!me) acc_add(v, SP_WS, n.ml_off, mln, false);
             acc_add(v, SP_WS, n.out_off, pos * outw, !bwd);
             if (bwd) {
+                // (under MST_BF_LOSS_FUSED the upstream gradient is not read; declaring the read keeps the generic path safe)
                 acc_add(v, SP_GRAD, n.g_out_off, pos * outw, false);
-                acc_add(v, SP_GRAD, n.g_oct_off, rows * ow, true);
-                acc_add(v, SP_GRAD, n.g_deg_off, rows * dw, true);
+                acc_add(v, SP_WS, n.loss_saved_off, MST_LOSS_SAVED, false);
+                acc_add(v, SP_WS, n.loss_gl_off, 64, false);
+                acc_add(v, SP_GRAD, n.itp_oct_off, (int64_t)n.nblk * n.C * ow, true);      // per-workgroup partial gradients of it
+                acc_add(v, SP_GRAD, n.itp_deg_off, (int64_t)n.nblk * n.C * dw, true);
                 acc_add(v, SP_GRAD, n.rt_oct_off, (int64_t)n.Q * NF * ow, true);       // channel sums of dL/dz = gradient of rt
                 acc_add(v, SP_GRAD, n.rt_deg_off, (int64_t)n.Q * NF * dw, true);
                 if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
@@ -1680,6 +1695,7 @@ static Bases make_bases(const mst_plan* p, const float* params, float* gparams, 
     b.p[SP_WS] = ws; b.p[SP_PAR] = const_cast<float*>(params); b.p[SP_GPAR] = gparams;
     b.p[SP_EXT0] = const_cast<float*>(pitched); b.p[SP_EXT1] = const_cast<float*>(unpitched);
     b.p[SP_GRAD] = ws + (int64_t)p->K() * p->act_top; b.p[SP_TMP] = ws + 2 * (int64_t)p->K() * p->act_top;
+    b.flags = 0;
     return b;
 }
 
@@ -1759,11 +1775,12 @@ extern "C" int32_t mst_zero_grads(const mst_plan* p, int32_t mask, float* ws, ms
     return MST_OK;
 }
 
-extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* params, float* gparams, float* ws,
-                                const float* pitched, const float* unpitched, mst_stream stream) {
+static int32_t backward_impl(const mst_plan* p, int32_t mask, const float* params, float* gparams, float* ws,
+                             const float* pitched, const float* unpitched, mst_stream stream, int32_t flags) {
     if (!p || !params || !gparams || !ws) return MST_ERR_ARG;
     if ((mask & MST_STAGE_EXTRACT) && (!pitched || (p->d.has_unpitched && !unpitched))) return MST_ERR_ARG;
-    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    b.flags = flags;
     {
         int e = run_pass(p, p->list(mask, 1), mask, b, (hipStream_t)stream);
         if (e) return e;
@@ -1776,6 +1793,11 @@ extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* pa
             return MST_ERR_LAUNCH;
     }
     return MST_OK;
+}
+
+extern "C" int32_t mst_backward(const mst_plan* p, int32_t mask, const float* params, float* gparams, float* ws,
+                                const float* pitched, const float* unpitched, mst_stream stream) {
+    return backward_impl(p, mask, params, gparams, ws, pitched, unpitched, stream, 0);
 }
 
 extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gparams, float* ws,
@@ -1802,10 +1824,11 @@ extern "C" int32_t mst_train_iteration(const mst_plan* p, const float* params, f
     e = loss_bwd_batched(ws + at("pitched_pred"), pitched, np, U ? ws + at("unpitched_pred") : nullptr, U ? unpitched : nullptr,
                          nu, ws + at("instruments_pred"), ws + at("used_instruments"), p->z.NI, ws + at("mode_pred"),
                          ws + at("mode"), ws + at("bpm_pred"), ws + at("bpm_target"), ws + p->t_saved.off,
-                         ws + p->t_gl.off, g + at("pitched_pred"), U ? g + at("unpitched_pred") : nullptr,
+                         ws + p->t_gl.off, nullptr /* the applier's backward kernel derives dL/d pitched_pred itself */,
+                         U ? g + at("unpitched_pred") : nullptr,
                          g + at("instruments_pred"), g + at("mode_pred"), g + at("bpm_pred"), lb, st);
     if (e) return e;
-    e = mst_backward(p, MST_STAGE_ALL, params, gparams, ws, pitched, unpitched, stream);
+    e = backward_impl(p, MST_STAGE_ALL, params, gparams, ws, pitched, unpitched, stream, MST_BF_LOSS_FUSED);
     if (e) return e;
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
@@ -2005,7 +2028,8 @@ extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t 
                                        int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes) {
     if (!p || !params || !ws || !ms || !kind || !flops || !bytes || reps < 1) return MST_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    if (backward && !p->tiled()) b.flags = MST_BF_LOSS_FUSED;          // what mst_train_iteration launches
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MST_ERR_ALLOC;
     std::vector<const Step*> steps;
