@@ -185,7 +185,9 @@ struct NotesDesc {
     int64_t it_oct_off, it_deg_off;      // (C, 240), (C, 210)
     // (the backward kernel sums dL/dz over the channels itself and writes the rt gradients at the same offsets in SP_GRAD)
     int64_t x_off; int32_t x_space;  // ME: pitched input
-    int64_t ml_off;              // PSA: (Q*F*56, ML)
+    int64_t mel_off, g_mel_off;  // PSA: melody (Q*F*56, W) [SP_WS] and its gradient [SP_GRAD]: melody_linear is applied inside the note kernels
+    int64_t wm_off;              // PSA: melody_linear.weight (ML x W), immediately followed by its bias (ML) [SP_PAR]
+    int64_t ml_off;              // (unused since round 3: the melody_linear activations are no longer materialised)
     int64_t wc_off, bc_off, wl_off, bl_off;   // params (ME: channels_linear, linear; PSA: linear only in wl/bl)
     int64_t out_off;             // ME: melody (Q,F,56,W), the channels already combined; PSA: (P,F,56,5)
     int64_t g_out_off, g_oct_off, g_deg_off, g_ml_off;   // PSA: g_oct / g_deg = gradient of the PRE-activations z, (P*F, 240 | 210)

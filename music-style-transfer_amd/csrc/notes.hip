@@ -345,15 +345,20 @@ __global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* _
 
 // ============================================================================ PitchedStyleApplier
 #define PSA_HW 30
-template <int ML>
+// (melody_linear — 8 -> 20 + leaky over (positions x 56) rows, style/model.py:606-610,660-662 — is applied HERE, per note, from the
+// melody row: the (positions x 56 x 20) tensor it produced in round 2 cost a kernel, a 2.9 MB write and two reads per clip)
+template <int ML, int MEL>
 __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
     __shared__ float w_s[NPF * KL], b_s[NPF];
+    __shared__ float wm_s[ML * MEL], bm_s[ML];
     __shared__ float lo_s[NOCT * PSA_HW], ld_s[NDEG * PSA_HW];
     const int tid = threadIdx.x;
     const float* par = b.p[SP_PAR];
     for (int i = tid; i < NPF * KL; i += 64) w_s[i] = par[d.wl_off + i];
+    for (int i = tid; i < ML * MEL; i += 64) wm_s[i] = par[d.wm_off + i];
+    if (tid < ML) bm_s[tid] = par[d.wm_off + ML * MEL + tid];
     if (tid < NPF) b_s[tid] = par[d.bl_off + tid];
     float* ws = b.p[SP_WS];
     const int QF = d.Q * NF;
@@ -384,13 +389,18 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
 #pragma unroll
         for (int i = 0; i < NPF; ++i) zm[i] = 0.f;
         if (n < NPN) {
-            const float* ml = ws + d.ml_off + ((int64_t)qf * NPN + n) * ML;
+            float mel[MEL];
+            ld_vec<MEL>(ws + d.mel_off + ((int64_t)qf * NPN + n) * MEL, mel);
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                float z = b_s[i];
+            for (int i = 0; i < NPF; ++i) zm[i] = b_s[i];
 #pragma unroll
-                for (int k = 0; k < ML; ++k) z = fmaf(w_s[i * KL + PSA_HW + k], ml[k], z);
-                zm[i] = z;
+            for (int k = 0; k < ML; ++k) {
+                float a = bm_s[k];
+#pragma unroll
+                for (int q = 0; q < MEL; ++q) a = fmaf(wm_s[k * MEL + q], mel[q], a);
+                const float mlk = lrelu(a);
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) zm[i] = fmaf(w_s[i * KL + PSA_HW + k], mlk, zm[i]);
             }
         }
         for (int c = 0; c < d.C; ++c) {
@@ -442,12 +452,17 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
 //     elementwise loss backward over the pitched tensor and its 2.9 MB per clip of gradient never exist.
 //   * the rt / it rows are fetched once per qf / once per workgroup instead of once per row.
 // The melody-linear columns need only the CHANNEL SUM of dz (ml does not depend on the channel): after the waves met,
-//   g_ml[qf][n][k] = sum_i dzsum[n][i] W[i][30 + k],  dW[i][30 + k] += dzsum[n][i] ml[qf][n][k],  db[i] += dzsum[n][i]
-// with lane = (k, note group), the groups dealt over all waves.  Two workgroup barriers per qf; every sum has a fixed order.
+//   g_ml[n][k] = sum_i dzsum[n][i] W[i][30 + k],  dW[i][30 + k] += dzsum[n][i] ml[n][k],  db[i] += dzsum[n][i]
+// with lane = (k, note group), the groups dealt over all waves — and melody_linear itself (ml = leaky(Wm mel + bm), 8 -> 20,
+// style/model.py:606-610,660-662) is differentiated right here: the lane recomputes ml[n][k] from the staged melody row, takes
+// gpre = g_ml leaky'(ml), accumulates dWm[k][:] += gpre mel[n][:] and dbm[k] += gpre, and after a wave-private exchange of gpre
+// the wave's lanes = (note, m) form the melody gradient g_mel[n][m] = sum_k gpre[n][k] Wm[k][m].  Neither ml nor its gradient
+// exists in memory any more (round 2: a 2.9 MB tensor per clip written once and read twice, its gradient written and read
+// once, and the two row-wise Linear launches around them).  Two workgroup barriers per qf; every sum has a fixed order.
 #ifndef PSA_BWD_MINW
 #define PSA_BWD_MINW 2
 #endif
-template <int ML, int NPB, bool LOSS>
+template <int ML, int MEL, int NPB, bool LOSS>
 __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
@@ -461,6 +476,9 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
     __shared__ __attribute__((aligned(16))) float dz_s[NPB][2][NPN][8];         // [wave][row A | B][note][5 used of 8]
     __shared__ float lo_s[NPB][NOCT][64];                                       // the pair's octave rows, [octave][lane]
     __shared__ __attribute__((aligned(16))) float dzs_s[NPN][8];                // dz summed over the channels of this qf
+    __shared__ __attribute__((aligned(16))) float mel_s[2][NPN][MEL];           // the qf's melody rows; two buffers: a wave may stage
+                                                                                // the next qf while another still reads this one
+    __shared__ float gp_s[NPN][ML + 1];                                         // gpre[n][k]; a wave reads back only the notes it wrote
     __shared__ float coef_s[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NP = blockDim.x >> 6, nthreads = blockDim.x;
     const int half = lane >> 5, jl = lane & 31;
@@ -491,6 +509,10 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
     float wm[NPF], dwm[NPF], dbm[NPF];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) { wm[i] = par[d.wl_off + i * KL + PSA_HW + k]; dwm[i] = 0.f; dbm[i] = 0.f; }
+    float wml[MEL], dwml[MEL], dbml = 0.f;                 // melody_linear row k: Wm[k][:], its gradient, d bm[k]
+#pragma unroll
+    for (int q = 0; q < MEL; ++q) { wml[q] = par[d.wm_off + k * MEL + q]; dwml[q] = 0.f; }
+    const float bml = par[d.wm_off + ML * MEL + k];
     if (LOSS) {
         // d total / d (TP FP FN SEvel SEdur BCE) of the pitched tensor from the loss tail's saved Jacobian (loss_bwd_kernel)
         if (tid < 8) {
@@ -516,7 +538,9 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
     // compiler kept two address registers per outstanding load and spilled ~300 bytes per lane at three waves per SIMD.
     typedef const MST_GLOBAL_AS float* gptr_t;
     const gptr_t y0 = (gptr_t)(ws + d.out_off), t0 = (gptr_t)tgt;
-    const gptr_t rto0 = (gptr_t)(ws + d.rt_oct_off), rtd0 = (gptr_t)(ws + d.rt_deg_off), ml0 = (gptr_t)(ws + d.ml_off);
+    const gptr_t rto0 = (gptr_t)(ws + d.rt_oct_off), rtd0 = (gptr_t)(ws + d.rt_deg_off), mel0 = (gptr_t)(ws + d.mel_off);
+    typedef float mel_f4 __attribute__((ext_vector_type(4)));
+    static_assert(MEL % 4 == 0 && NPN * MEL / 4 <= 64 * NPB * 2, "melody rows staged with at most two 16-byte loads per lane");
     struct QfIn { float rt[NOD], y[NSLOT], t[NSLOT]; };
     // flat element e = lane + 64 q of the pair's (row A | row B): q < 4 lies in row A, q > 4 in row B, q = 4 straddles
     const unsigned rowA = (unsigned)((2 * wv < d.C ? 2 * wv : 0) * QF) * ROWE + lane;
@@ -541,6 +565,7 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
     bool have = qf < QF;                                   // workgroup-uniform
     QfIn cur;
     if (have) fetch(qf, cur);
+    int par_q = 0;
     while (have) {
         const int nqf = qf + gridDim.x;
         const bool nhave = nqf < QF;
@@ -622,11 +647,14 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
         }
 #pragma unroll
         for (int o = 0; o < NOCT; ++o) acc_it[o] += rto[o][lane];                // (lane-private slots, static register indices)
-        float mlv[MAXN];                                   // this lane's melody-linear activations of the qf: needed after the barriers
-#pragma unroll
-        for (int u = 0; u < MAXN; ++u) {
-            const int n = G + u * NGT;
-            mlv[u] = ml0[((unsigned)qf * NPN + ((mact && n < NPN) ? n : 0)) * ML + k];
+        // the qf's melody rows (56 x MEL, contiguous): 16-byte pieces dealt over the workgroup, in LDS before the first barrier
+        {
+            constexpr int NPIECE = NPN * MEL / 4;
+            for (int e = tid; e < NPIECE; e += nthreads) {
+                const mel_f4 v = *reinterpret_cast<const MST_GLOBAL_AS mel_f4*>(mel0 + ((unsigned)qf * NPN * MEL + 4 * e));
+                float* dst = &mel_s[par_q][0][0] + 4 * e;
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            }
         }
         if (nhave) fetch(nqf, cur);                        // the next qf's operands: in flight from here to the top of the loop
 #pragma unroll
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
             dzs_s[n][i] = a;
         }
         __syncthreads();
-        // ---- the melody-linear columns from the channel sums
+        // ---- the melody-linear columns from the channel sums, and melody_linear's own backward
         if (mact) {
 #pragma unroll
             for (int u = 0; u < MAXN; ++u) {
@@ -664,15 +692,41 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
                     const float s5 = dzs_s[n][4];
                     float gm = s4.x * wm[0];
                     gm = fmaf(s4.y, wm[1], gm); gm = fmaf(s4.z, wm[2], gm); gm = fmaf(s4.w, wm[3], gm); gm = fmaf(s5, wm[4], gm);
-                    gr[d.g_ml_off + ((int64_t)qf * NPN + n) * ML + k] = gm;      // sole writer (all channels already summed)
-                    const float mv = mlv[u];
+                    float mel[MEL];
+                    ld_vec<MEL>(&mel_s[par_q][n][0], mel);
+                    float a = bml;
+#pragma unroll
+                    for (int q = 0; q < MEL; ++q) a = fmaf(wml[q], mel[q], a);      // same chain as the forward kernel
+                    const float mv = lrelu(a);
                     dwm[0] = fmaf(s4.x, mv, dwm[0]); dwm[1] = fmaf(s4.y, mv, dwm[1]); dwm[2] = fmaf(s4.z, mv, dwm[2]);
                     dwm[3] = fmaf(s4.w, mv, dwm[3]); dwm[4] = fmaf(s5, mv, dwm[4]);
                     dbm[0] += s4.x; dbm[1] += s4.y; dbm[2] += s4.z; dbm[3] += s4.w; dbm[4] += s5;
+                    const float gpre = gm * dlrelu(mv);
+#pragma unroll
+                    for (int q = 0; q < MEL; ++q) dwml[q] = fmaf(gpre, mel[q], dwml[q]);
+                    dbml += gpre;
+                    gp_s[n][k] = gpre;
                 }
             }
         }
-        qf = nqf; have = nhave;
+        MST_WAVE_SYNC();
+        // g_mel[n][m] = sum_k gpre[n][k] Wm[k][m] for the notes of THIS wave's groups (n = wv * NG + g + u * NGT): lane = (note, m)
+        {
+            const float* wmf = par + d.wm_off;
+            constexpr int NITEM = MAXN * NG * MEL;
+            for (int e = lane; e < NITEM; e += 64) {
+                const int m = e % MEL, t = e / MEL;        // t = (u, g)
+                const int u = t / NG, g = t - u * NG;
+                const int n = wv * NG + g + u * NGT;
+                if (n < NPN) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < ML; ++kk) a = fmaf(gp_s[n][kk], wmf[kk * MEL + m], a);
+                    gr[d.g_mel_off + ((int64_t)qf * NPN + n) * MEL + m] = a;       // sole writer: the applier is melody's only consumer
+                }
+            }
+        }
+        qf = nqf; have = nhave; par_q ^= 1;
         // (no barrier here: the next qf's wave-private writes follow its readers by the two barriers above; dzs_s is rewritten
         // only behind the next qf's first barrier)
     }
@@ -685,9 +739,10 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
 #pragma unroll
         for (int q = 0; q < NDEG; ++q) pd[q * PSA_HW] = acc_it[NOCT + q];
     }
-    // ---- one slab row per workgroup: linear.weight (5 x KL) then linear.bias (5); partial sums meet in a fixed order
-    constexpr int NWT = NPF * KL + NPF;
-    static_assert(NWT <= 2 * NPN * 8 && NPF * 64 <= 4 * ROWE, "slab row wider than the staging it reuses");
+    // ---- one slab row per workgroup, in parameter order: melody_linear.weight (ML x MEL), melody_linear.bias (ML), linear.weight
+    // (5 x KL), linear.bias (5); partial sums meet in a fixed order
+    constexpr int NML = ML * MEL + ML, NWT = NML + NPF * KL + NPF;
+    static_assert(NWT <= 2 * NPN * 8 && (MEL + 1) * 64 <= 4 * ROWE, "slab row wider than the staging it reuses");
     __syncthreads();                                       // all LDS staging is free now
     float* wsum = &dz_s[wv][0][0][0];                      // NWT floats per wave
     float (*red)[64] = reinterpret_cast<float (*)[64]>(&raw_s[wv][0][0]);
@@ -696,7 +751,7 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
     MST_WAVE_SYNC();
     if (lane < PSA_HW) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) wsum[i * KL + lane] = red[i][lane] + red[i][lane + 32];
+        for (int i = 0; i < NPF; ++i) wsum[NML + i * KL + lane] = red[i][lane] + red[i][lane + 32];
     }
     MST_WAVE_SYNC();
 #pragma unroll
@@ -708,7 +763,7 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
             float a = red[i][lane];
 #pragma unroll
             for (int gq = 1; gq < NG; ++gq) a += red[i][lane + gq * ML];
-            wsum[i * KL + PSA_HW + lane] = a;
+            wsum[NML + i * KL + PSA_HW + lane] = a;
         }
     }
     MST_WAVE_SYNC();
@@ -719,7 +774,21 @@ __global__ __launch_bounds__(64 * NPB, PSA_BWD_MINW) void psa_bwd2_kernel(const 
         float a = red[lane][0];
 #pragma unroll
         for (int gq = 1; gq < NG; ++gq) a += red[lane][gq * ML];
-        wsum[NPF * KL + lane] = a;
+        wsum[NML + NPF * KL + lane] = a;
+    }
+    MST_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < MEL; ++q) red[q][lane] = mact ? dwml[q] : 0.f;
+    red[MEL][lane] = mact ? dbml : 0.f;
+    MST_WAVE_SYNC();
+    if (lane < ML) {                                       // lane = k: the note groups' partial sums in group order
+#pragma unroll
+        for (int q = 0; q <= MEL; ++q) {
+            float a = red[q][lane];
+#pragma unroll
+            for (int gq = 1; gq < NG; ++gq) a += red[q][lane + gq * ML];
+            if (q < MEL) wsum[lane * MEL + q] = a; else wsum[ML * MEL + lane] = a;
+        }
     }
     __syncthreads();
     for (int w = tid; w < NWT; w += nthreads) {
@@ -741,8 +810,8 @@ bool notes_widths_supported(int W, int CW, int ML) {
     else if (h.W == 4 && h.CW == 5) hipLaunchKernelGGL((KERN<4, 5>), GRID, BLOCK, 0, s, dev, b);      \
     else return MST_ERR_UNSUPPORTED;
 #define PSA_DISPATCH(KERN, GRID, BLOCK)                                                             \
-    if (h.ML == 20) hipLaunchKernelGGL((KERN<20>), GRID, BLOCK, 0, s, dev, b);                        \
-    else if (h.ML == 14) hipLaunchKernelGGL((KERN<14>), GRID, BLOCK, 0, s, dev, b);                   \
+    if (h.ML == 20 && h.W == 8) hipLaunchKernelGGL((KERN<20, 8>), GRID, BLOCK, 0, s, dev, b);         \
+    else if (h.ML == 14 && h.W == 4) hipLaunchKernelGGL((KERN<14, 4>), GRID, BLOCK, 0, s, dev, b);    \
     else return MST_ERR_UNSUPPORTED;
 
 #define ME_RED_DISPATCH(BWD, GRID, BLOCK)                                                              \
@@ -771,20 +840,20 @@ int launch_psa_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Ba
     return (int)hipGetLastError();
 }
 int psa_bwd_waves(int C) { return (C + 1) / 2; }      // one wave per channel pair
-#define PSA_BWD_LAUNCH(ML_, NPB_)                                                                                               \
+#define PSA_BWD_LAUNCH(ML_, MEL_, NPB_)                                                                                         \
     {                                                                                                                           \
-        if (b.flags & MST_BF_LOSS_FUSED) hipLaunchKernelGGL((psa_bwd2_kernel<ML_, NPB_, true>), grid, dim3(64 * np), 0, s, dev, b);   \
-        else hipLaunchKernelGGL((psa_bwd2_kernel<ML_, NPB_, false>), grid, dim3(64 * np), 0, s, dev, b);                          \
+        if (b.flags & MST_BF_LOSS_FUSED) hipLaunchKernelGGL((psa_bwd2_kernel<ML_, MEL_, NPB_, true>), grid, dim3(64 * np), 0, s, dev, b);   \
+        else hipLaunchKernelGGL((psa_bwd2_kernel<ML_, MEL_, NPB_, false>), grid, dim3(64 * np), 0, s, dev, b);                    \
     }
-#define PSA_BWD_BUCKETS(ML_)                                                                        \
-    if (np <= 1) PSA_BWD_LAUNCH(ML_, 1) else if (np <= 2) PSA_BWD_LAUNCH(ML_, 2) else if (np <= 4) PSA_BWD_LAUNCH(ML_, 4)  \
-    else if (np <= 8) PSA_BWD_LAUNCH(ML_, 8) else PSA_BWD_LAUNCH(ML_, 16)
+#define PSA_BWD_BUCKETS(ML_, MEL_)                                                                  \
+    if (np <= 1) PSA_BWD_LAUNCH(ML_, MEL_, 1) else if (np <= 2) PSA_BWD_LAUNCH(ML_, MEL_, 2) else if (np <= 4) PSA_BWD_LAUNCH(ML_, MEL_, 4)  \
+    else if (np <= 8) PSA_BWD_LAUNCH(ML_, MEL_, 8) else PSA_BWD_LAUNCH(ML_, MEL_, 12)
 int launch_psa_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
     const int np = psa_bwd_waves(h.C);
-    if (np > 16) return MST_ERR_UNSUPPORTED;
+    if (np > 12) return MST_ERR_UNSUPPORTED;         // 24 pitched channels (a MIDI file has 16 channels in all): the LDS of one workgroup
     const dim3 grid(h.nblk, count);
-    if (h.ML == 20) { PSA_BWD_BUCKETS(20) }
-    else if (h.ML == 14) { PSA_BWD_BUCKETS(14) }
+    if (h.ML == 20 && h.W == 8) { PSA_BWD_BUCKETS(20, 8) }
+    else if (h.ML == 14 && h.W == 4) { PSA_BWD_BUCKETS(14, 4) }
     else return MST_ERR_UNSUPPORTED;
     return (int)hipGetLastError();
 }

@@ -163,7 +163,9 @@ static void build_params(const mst_dims& d, const Sizes& z, ParamTable& t) {
 }
 
 static bool dims_ok(const mst_dims* d) {
-    return d && d->C >= 1 && d->C <= COMBINE_MAXC && d->R >= 1 && d->T >= 1 && d->beat >= 1 && d->bar >= 2 &&
+    // C <= 24: the applier's backward kernel runs one wave per channel pair of a qf in ONE workgroup (LDS of 12 waves); a MIDI file
+    // has 16 channels, so the reference's own inputs stop at 15 pitched channels
+    return d && d->C >= 1 && d->C <= COMBINE_MAXC && d->C <= 24 && d->R >= 1 && d->T >= 1 && d->beat >= 1 && d->bar >= 2 &&
            d->bar % 2 == 0 && d->nrf >= 1 && d->style >= 1 && d->melody >= 1 && d->rhythm >= 1 && d->instr >= 1 &&
            d->n_instruments >= 1 && d->clips >= 0 && d->clips <= 4096;
 }
@@ -318,7 +320,7 @@ struct mst_plan {
     }
     NotesDesc reloc(NotesDesc n, int k) const {
         const int64_t a = shift(SP_WS, k), t = shift(SP_TMP, k);
-        n.oct_off += a; n.deg_off += a; n.rt_oct_off += a; n.rt_deg_off += a; n.it_oct_off += a; n.it_deg_off += a; n.ml_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
+        n.oct_off += a; n.deg_off += a; n.rt_oct_off += a; n.rt_deg_off += a; n.it_oct_off += a; n.it_deg_off += a; n.mel_off += a; n.g_mel_off += a; n.out_off += a; n.g_out_off += a; n.g_oct_off += a; n.g_deg_off += a;
         n.g_ml_off += a; n.x_off += shift(n.x_space, k); n.slab_off += t; n.part_off += t; n.stats_off += t;
         n.itp_oct_off += a; n.itp_deg_off += a; n.loss_saved_off += a; n.loss_gl_off += a;
         return n;
@@ -1041,23 +1043,27 @@ void mst_plan::build() {
         column_sum(op, itp_x[which].off, C * Nw, psa_nblk, C * Nw, it_x[which].off);
         ops.push_back(op);
     }
-    T ml = rowlin(AP, melody, true, m + ".melody_linear", z.PSA_ML, ACT_LEAKY);
+    // melody_linear (W -> ML, leaky; style/model.py:606-610,660-662) has no op of its own: the note kernels apply it per note
     T xp = newT(P_ * NF * NPN, NPF, "pitched_pred");
     {
         NotesDesc n{}; n.C = C; n.Q = Q_; n.W = z.MEL; n.CW = z.ME_CW; n.ML = z.PSA_ML;
-        n.rt_oct_off = rt_x[0].off; n.rt_deg_off = rt_x[1].off; n.it_oct_off = it_x[0].off; n.it_deg_off = it_x[1].off; n.ml_off = ml.off;
+        n.rt_oct_off = rt_x[0].off; n.rt_deg_off = rt_x[1].off; n.it_oct_off = it_x[0].off; n.it_deg_off = it_x[1].off;
+        n.mel_off = melody.off; n.g_mel_off = melody.off; n.wm_off = pt.off(m + ".melody_linear.weight");
         n.wl_off = pt.off(m + ".linear.weight"); n.bl_off = pt.off(m + ".linear.bias");
-        n.out_off = xp.off; n.g_out_off = xp.off; n.g_ml_off = ml.off;
+        if (pt.off(m + ".melody_linear.bias") != n.wm_off + (int64_t)z.PSA_ML * z.MEL || n.wl_off != n.wm_off + (int64_t)z.PSA_ML * z.MEL + z.PSA_ML ||
+            n.bl_off != n.wl_off + (int64_t)NPF * (NPF * 6 + z.PSA_ML))
+            err = MST_ERR_UNSUPPORTED;                        // the slab row below is these four parameters back to back
+        n.out_off = xp.off; n.g_out_off = xp.off;
         n.itp_oct_off = itp_x[0].off; n.itp_deg_off = itp_x[1].off;
         n.x_space = SP_EXT0; n.x_off = 0;                     // the target of the fused loss backward: the pitched input itself
         n.loss_saved_off = t_saved.off; n.loss_gl_off = t_gl.off;
-        const int nw = NPF * (NPF * 6 + z.PSA_ML) + NPF;
+        const int nw = z.PSA_ML * z.MEL + z.PSA_ML + NPF * (NPF * 6 + z.PSA_ML) + NPF;
         n.nblk = psa_nblk; n.slab_stride = nw; n.slab_off = tmp((int64_t)nw * n.nblk);
         Op op; op.stage = AP;
         op.fwd.push_back(Step{K_PSA_F, (int)notes.size(), 1, 0, 0});
         op.bwd.push_back(Step{K_PSA_B, (int)notes.size(), 1, 0, 0});
         notes.push_back(n); ops.push_back(op);
-        slabs[2].push_back(SlabEntry{n.wl_off, n.slab_off, nw, nw, n.nblk});
+        slabs[2].push_back(SlabEntry{n.wm_off, n.slab_off, nw, nw, n.nblk});
     }
     if (U) {
         m = "unpitched_style_applier";
@@ -1286,12 +1292,12 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             const int64_t pos = (int64_t)n.C * n.Q * NF * NPN;
             const int64_t rows = me ? (int64_t)n.C * n.Q : (int64_t)n.C * n.Q * NF;
             const int ow = me ? NOCT * n.W : NOCT * 30, dw = me ? NDEG * n.W : NDEG * 30, outw = me ? n.W : NPF;
-            const int64_t mln = (int64_t)n.Q * NF * NPN * n.ML;
+            const int64_t mln = (int64_t)n.Q * NF * NPN * n.W;            // melody rows (melody_linear is applied inside the kernels)
             acc_add(v, SP_WS, n.rt_oct_off, (int64_t)n.Q * NF * ow, false);
             acc_add(v, SP_WS, n.rt_deg_off, (int64_t)n.Q * NF * dw, false);
             acc_add(v, SP_WS, n.it_oct_off, (int64_t)n.C * ow, false);
             acc_add(v, SP_WS, n.it_deg_off, (int64_t)n.C * dw, false);
-            if (!me) acc_add(v, SP_WS, n.ml_off, mln, false);
+            if (!me) acc_add(v, SP_WS, n.mel_off, mln, false);
             acc_add(v, SP_WS, n.out_off, pos * outw, !bwd);
             if (bwd) {
                 // (under MST_BF_LOSS_FUSED the upstream gradient is not read; declaring the read keeps the generic path safe)
@@ -1302,7 +1308,7 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
                 acc_add(v, SP_GRAD, n.itp_deg_off, (int64_t)n.nblk * n.C * dw, true);
                 acc_add(v, SP_GRAD, n.rt_oct_off, (int64_t)n.Q * NF * ow, true);       // channel sums of dL/dz = gradient of rt
                 acc_add(v, SP_GRAD, n.rt_deg_off, (int64_t)n.Q * NF * dw, true);
-                if (!me) acc_add(v, SP_GRAD, n.g_ml_off, mln, true);
+                if (!me) acc_add(v, SP_GRAD, n.g_mel_off, mln, true);
                 acc_add(v, SP_TMP, n.slab_off, (int64_t)n.slab_stride * n.nblk, true);
             }
             break;
