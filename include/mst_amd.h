@@ -205,6 +205,29 @@ int32_t mst_plan_time_steps(const mst_plan* p, int32_t stage_mask, int32_t backw
                             float* gparams, float* ws, const float* pitched, const float* unpitched,
                             mst_stream stream, int32_t reps, float* ms, int32_t* kind, double* flops, double* bytes);
 
+/* ---- AUDIO EXTENSION — NOT REFERENCE PARITY.  The reference has no audio path (latex/music-style-transfer.tex:79-80 names it as
+ * future work; requirements.txt:1-8 has no audio library); BASELINE.json's metric text nevertheless speaks of 30 s @ 44.1 kHz clips,
+ * an STFT(1024/256) featuriser and a feature-Gram style loss, and SURVEY.md 8(f4) keeps that as an optional extension with a
+ * build-defined oracle (oracle/audio_oracle.py: torch.stft / matmul / autograd on the CPU; parity unpinned).  Nothing of the hot
+ * path above uses these entry points.
+ * Layout: a clip of n_samples mono float samples -> frames = 1 + n_samples / hop frames (centre-padded by reflection, periodic Hann
+ * window: torch.stft's defaults) x bins = n_fft / 2 + 1; magnitude / feature matrices are (frames x ld) row-major with
+ * ld = bins rounded up to a multiple of 8 and zero pad columns; Gram matrices are (ld x ld), pads zero. */
+typedef struct mst_audio_plan mst_audio_plan;
+mst_audio_plan* mst_audio_plan_create(int32_t n_fft /* 1024 | 2048 */, int32_t hop, int64_t n_samples, int32_t* status);
+void mst_audio_plan_destroy(mst_audio_plan* p);
+/* out = {frames, bins, ld, workspace floats of mst_audio_gram / mst_audio_style_iteration, k-splits of the Gram, Gram tiles} */
+int32_t mst_audio_plan_info(const mst_audio_plan* p, int64_t out[6]);
+/* spec: frames x bins complex64 (re, im interleaved) or NULL; mag: frames x ld or NULL (at least one) */
+int32_t mst_audio_stft(const mst_audio_plan* p, const float* audio, float* spec, float* mag, mst_stream stream);
+/* gram = feat^T feat / frames (ld x ld) on the f32 matrix cores; ws: workspace (mst_audio_plan_info) */
+int32_t mst_audio_gram(const mst_audio_plan* p, const float* feat, float* gram, float* ws, mst_stream stream);
+/* One optimisation iteration on x (frames x ld): loss = || x^T x / frames - gram_style ||_F^2 (written to *loss, a device float),
+ * grad = (4 / frames) x (x^T x / frames - gram_style) (written to `grad`, frames x ld), then Adam(lr, .9, .999, 1e-8) on x with
+ * state tensors exp_avg / exp_avg_sq (frames x ld) and `state` (4 floats, as mst_adam_step). */
+int32_t mst_audio_style_iteration(const mst_audio_plan* p, float* x, const float* gram_style, float* grad, float* exp_avg,
+                                  float* exp_avg_sq, float* state, float* ws, float* loss, double lr, mst_stream stream);
+
 /* test hook of the plan builder's single-launch weight-gradient reduction guard: do two column blocks of one row-major matrix
  * (row pitch ld), given by their first elements' offsets from the matrix's element (0, 0), share no element?  1 = disjoint. */
 int32_t mst_debug_slab_columns_disjoint(int64_t off_x, int32_t width_x, int64_t off_y, int32_t width_y, int32_t ld);

@@ -106,6 +106,12 @@ _SIGS = {
     'mst_plan_step_info': (C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
     'mst_plan_step_gemms': (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     'mst_plan_time_steps': (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    'mst_audio_plan_create': (_P, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]),
+    'mst_audio_plan_destroy': (None, [_P]),
+    'mst_audio_plan_info': (C.c_int32, [_P, C.POINTER(C.c_int64 * 6)]),
+    'mst_audio_stft': (C.c_int32, [_P, _P, _P, _P, _P]),
+    'mst_audio_gram': (C.c_int32, [_P, _P, _P, _P, _P]),
+    'mst_audio_style_iteration': (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, _P]),
     'mst_version': (C.c_char_p, []),
 }
 
