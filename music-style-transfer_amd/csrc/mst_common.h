@@ -10,6 +10,12 @@
 #ifndef MST_GLOBAL_AS
 #define MST_GLOBAL_AS __attribute__((address_space(1)))
 #endif
+// constant-address-space qualifier for WAVE-UNIFORM read-only data (the tiny weight matrices of the note kernels): loads through
+// such a pointer are scalar loads (s_load_dword*) into SGPRs, which every lane's FMA reads as an operand — held in vector
+// registers the same weights cost ~170 VGPRs per lane and the second wave per SIMD.  The interpreter pre-defines it as nothing.
+#ifndef MST_CONST_AS
+#define MST_CONST_AS __attribute__((address_space(4)))
+#endif
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, then s_barrier.  Unlike
 // __syncthreads() it does not drain vmcnt, so global prefetches / streamed stores issued around
 // it stay in flight (on MI355X the vmcnt(0) of __syncthreads() cost ~1-4 us per LSTM step).

@@ -54,17 +54,16 @@ __device__ __forceinline__ void st_vec(float* p, const float (&v)[N]) {
     for (int i = 0; i < N / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
-// the small weights of the melody encoder's note tail, staged once per workgroup
+// the small weights of the melody encoder's note tail: wave-uniform, read through constant-address-space pointers, i.e. by
+// scalar loads into SGPRs (they are parameters: nothing writes them while a pass runs).  Staged in LDS and hoisted into
+// vector registers by the compiler, as in round 2, they took ~170 VGPRs of every lane and held these kernels at two waves per SIMD.
 template <int W, int CW>
 struct MeWeights {
     static constexpr int KL = W + CW;
-    float wc[CW * NPF], bc[CW], wl[W * KL], bl[W];
-    __device__ __forceinline__ void load(const NotesDesc& d, const float* par, int tid) {
-        for (int i = tid; i < CW * NPF; i += 256) wc[i] = par[d.wc_off + i];
-        for (int i = tid; i < CW; i += 256) bc[i] = par[d.bc_off + i];
-        for (int i = tid; i < W * KL; i += 256) wl[i] = par[d.wl_off + i];
-        for (int i = tid; i < W; i += 256) bl[i] = par[d.bl_off + i];
-    }
+    typedef const MST_CONST_AS float* cptr;
+    cptr wc, bc, wl, bl;
+    __device__ __forceinline__ MeWeights(const NotesDesc& d, const float* par)
+        : wc((cptr)(par + d.wc_off)), bc((cptr)(par + d.bc_off)), wl((cptr)(par + d.wl_off)), bl((cptr)(par + d.bl_off)) {}
 };
 
 // One note of one channel: cat (W + CW) and x_c (W).  The octave / degree half of cat — and with it the first W terms of the
@@ -116,10 +115,8 @@ __device__ __forceinline__ void ld_x5(const float* x, int64_t item, float (&x5)[
 template <int W, int CW, bool BWD>
 __global__ __launch_bounds__(256) void me_reduce_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
-    __shared__ MeWeights<W, CW> wt;
+    const MeWeights<W, CW> wt(d, b.p[SP_PAR]);
     const int tid = threadIdx.x;
-    wt.load(d, b.p[SP_PAR], tid);
-    __syncthreads();
     const int lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
     if (g >= d.C * d.nwc) return;                          // wave-uniform
     const int c = g / d.nwc, i0 = g - c * d.nwc;
@@ -173,14 +170,18 @@ __global__ __launch_bounds__(256) void me_reduce_kernel(const NotesDesc* __restr
 // melody[q] = sum_c x_c[q] n_c / S: one wave per (q, half of the fractions), all channels recomputed; the first wave
 // also leaves n_c, S for the backward
 #define ME_FH 2
+#ifndef ME_FWD_MINW
+#define ME_FWD_MINW 4
+#endif
+#ifndef ME_BWD_MINW
+#define ME_BWD_MINW 3
+#endif
 template <int W, int CW>
-__global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+__global__ __launch_bounds__(256, ME_FWD_MINW) void me_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
-    __shared__ MeWeights<W, CW> wt;
+    const MeWeights<W, CW> wt(d, b.p[SP_PAR]);
     __shared__ float nc_s[4][COMBINE_MAXC + 1];
     const int tid = threadIdx.x;
-    wt.load(d, b.p[SP_PAR], tid);
-    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6, gw = blockIdx.x * 4 + wv;
     const int q = gw / ME_FH, fh = gw - q * ME_FH;
     if (q >= d.Q) return;                                   // wave-uniform
@@ -199,56 +200,46 @@ __global__ __launch_bounds__(256) void me_notes_fwd_kernel(const NotesDesc* __re
     const float* x = b.p[d.x_space] + d.x_off;
     float* ws = b.p[SP_WS];
     constexpr int F0 = NF / ME_FH;
-    static_assert(NF % ME_FH == 0, "equal halves");
-    const int f_begin = fh * F0;
-    // channels outside, the half's fractions inside: the octave / degree part of a channel's position is computed once (me_pos)
-    // and serves all its fractions; per (fraction, feature) the channels are still added in channel order
-    float acc[F0][W];
+    const int f_begin = fh * F0, f_end = fh == ME_FH - 1 ? NF : f_begin + F0;
+    // fractions outside, channels inside (one accumulator row live): the octave / degree half is recomputed per (fraction, channel)
+    // here — keeping it across the half's five fractions needs five accumulator rows and costs two of the four waves per SIMD
+    for (int f = f_begin; f < f_end; ++f) {
+        float acc[W];
 #pragma unroll
-    for (int ff = 0; ff < F0; ++ff)
-#pragma unroll
-        for (int j = 0; j < W; ++j) acc[ff][j] = 0.f;
-    for (int c = 0; c < d.C; ++c) {
-        const int64_t p = (int64_t)c * d.Q + q;
-        float octv[W], degv[W], cat_od[W], pre[W];
-        ld_vec<W>(ws + d.oct_off + (p * NOCT + o) * W, octv);
-        ld_vec<W>(ws + d.deg_off + (p * NDEG + dg) * W, degv);
-        me_pos<W, CW>(wt, octv, degv, cat_od, pre);
-        const float nc = nc_s[wv][c];
-#pragma unroll
-        for (int ff = 0; ff < F0; ++ff) {
-            float x5[NPF], catx[CW], out[W];
-            ld_x5(x, (p * NF + f_begin + ff) * NPN + n, x5);
+        for (int j = 0; j < W; ++j) acc[j] = 0.f;
+        for (int c = 0; c < d.C; ++c) {
+            const int64_t p = (int64_t)c * d.Q + q;
+            float octv[W], degv[W], cat_od[W], pre[W], x5[NPF], catx[CW], out[W];
+            ld_vec<W>(ws + d.oct_off + (p * NOCT + o) * W, octv);
+            ld_vec<W>(ws + d.deg_off + (p * NDEG + dg) * W, degv);
+            ld_x5(x, (p * NF + f) * NPN + n, x5);
+            me_pos<W, CW>(wt, octv, degv, cat_od, pre);
             me_frac<W, CW>(wt, pre, x5, catx, out);
+            const float nc = nc_s[wv][c];
 #pragma unroll
-            for (int j = 0; j < W; ++j) acc[ff][j] = fmaf(out[j], nc, acc[ff][j]);
+            for (int j = 0; j < W; ++j) acc[j] = fmaf(out[j], nc, acc[j]);
         }
-    }
-    const float rS = 1.f / S;
+        const float rS = 1.f / S;
 #pragma unroll
-    for (int ff = 0; ff < F0; ++ff) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) acc[ff][j] = acc[ff][j] * rS;
-        if (valid) st_vec<W>(ws + d.out_off + (((int64_t)q * NF + f_begin + ff) * NPN + n) * W, acc[ff]);
+        for (int j = 0; j < W; ++j) acc[j] = acc[j] * rS;
+        if (valid) st_vec<W>(ws + d.out_off + (((int64_t)q * NF + f) * NPN + n) * W, acc);
     }
 }
 
 // One wave per (position, half of the fractions): the two waves of a position are neighbours in one workgroup and meet
 // once, at the end of the position, to add their octave / degree partial sums (fixed order: half 0 + half 1).
 template <int W, int CW>
-__global__ __launch_bounds__(256, 2) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
+__global__ __launch_bounds__(256, ME_BWD_MINW) void me_notes_bwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = W + CW;
     constexpr int R_WC = 0, R_BC = CW * NPF, R_WL = R_BC + CW, R_BL = R_WL + W * KL;
     static_assert(KL + 1 <= 16 && W <= 16 && CW <= 16, "one 16x16 MFMA tile per product");
     // transposed staging rows of one wave: gm (W) | cat (KL) | gc (CW) | x (5) | god (W)
     constexpr int T_GM = 0, T_CAT = W, T_GC = W + KL, T_X = T_GC + CW, T_GOD = T_X + NPF, T_ROWS = T_GOD + W;
-    __shared__ MeWeights<W, CW> wt;
+    const MeWeights<W, CW> wt(d, b.p[SP_PAR]);
     __shared__ float tr[4][T_ROWS][NT_ROW];
     __shared__ float od_s[2][4][64];                       // octave | degree partial sums of the odd wave of each pair
     const int tid = threadIdx.x;
-    wt.load(d, b.p[SP_PAR], tid);
-    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6, pair = wv >> 1, fh = wv & 1;
     const bool valid = lane < NPN;
     const int n = valid ? lane : NPN - 1, o = n / NDEG, dg = n - o * NDEG;
