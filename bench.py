@@ -310,7 +310,128 @@ def surface_leg(dev, clip, iters, warm):
                             final_total_loss=float(packed.cpu()[0])))
 
 
+def audio_leg(nat, dev, iters, warm, cpu_seconds):
+    """AUDIO EXTENSION — not the headline, not reference parity (the reference has no audio path).  BASELINE.json's
+    metric text taken literally: a 30 s @ 44.1 kHz clip, STFT(1024/256) -> 5168 x 513 magnitudes, one optimisation iteration =
+    Gram of x, loss || G(x) - G_style ||^2, gradient (4/T) x (G - G_s), Adam on x; replayed from a hipGraph.  Reported under its
+    own key with its own rooflines (STFT: HBM; Gram / gradient GEMMs: f32 MFMA)."""
+    from style.audio import AudioPlan
+    n = 30 * 44100
+    plan = AudioPlan(n, 1024, 256, device=dev)
+    g = torch.Generator().manual_seed(3)
+    audio = (torch.rand(n, generator=g) * 2 - 1).to(dev)
+    style_audio = (torch.rand(n, generator=g) * 2 - 1).to(dev)
+    stream = torch.cuda.Stream(dev)
+
+    def timed_us(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+        for _ in range(reps):
+            fn()
+        e1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    with torch.cuda.stream(stream):
+        stft_us = timed_us(lambda: plan.stft(audio), 50)
+        stft_mag_us = timed_us(lambda: plan.stft(audio, want_spec=False), 50)
+        _, mag = plan.stft(audio, want_spec=False)
+        _, smag = plan.stft(style_audio, want_spec=False)
+        gram_us = timed_us(lambda: plan.gram(mag), 50)
+        gs = plan.gram(smag).clone()
+        x = mag.clone()
+        opt = plan.optimizer_state()
+        plan.style_iteration(x, gs, opt)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            plan.style_iteration(x, gs, opt)
+        for _ in range(warm):
+            graph.replay()
+        torch.cuda.synchronize()
+        first_loss = float(opt['loss'].cpu()[0])
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        last_loss = float(opt['loss'].cpu()[0])
+    T, F, ld = plan.frames, plan.bins, plan.ld
+    stft_bytes = 4 * n + 8 * T * F
+    gram_flops = 2.0 * T * F * (F + 1) / 2            # the symmetric half that is computed (lower-triangle tiles)
+    it_flops = gram_flops + 2.0 * T * ld * ld
+    out = dict(label='AUDIO EXTENSION - not reference parity (the reference has no audio path); oracle build-defined, parity unpinned',
+               metric='style-transfer opt iters/sec (spectrogram Gram loss, 30 s @ 44.1 kHz, STFT 1024/256)', value=iters / dt, unit='iters/s',
+               ms_per_step=dt / iters * 1e3, steps=iters, warmup=warm, hip_graph=True, dtype='f32', data='synthetic (uniform noise clips)',
+               config=dict(workload='x (5168 x 513 magnitudes, resident in HBM) optimised towards the Gram of a second clip: Gram GEMM '
+                                    '(k-split, lower-triangle 128x128 tiles) + finalise/loss + gradient GEMM + Adam per iteration',
+                           frames=T, bins=F, ld=ld, gram_k_splits=plan.splits, loss_first=first_loss, loss_last=last_loss),
+               stft=dict(us_complex_and_magnitude=stft_us, us_magnitude_only=stft_mag_us,
+                         roofline=dict(bound='hbm', achieved=stft_bytes / (stft_us * 1e-6) / 1e9, peak=PEAK_HBM_GBS, unit='GB/s',
+                                       frac=stft_bytes / (stft_us * 1e-6) / 1e9 / PEAK_HBM_GBS, algorithmic_bytes=stft_bytes,
+                                       timer='HIP events around 50 back-to-back launches', traffic=None)),
+               gram=dict(us=gram_us, roofline=dict(bound='mfma', achieved=gram_flops / (gram_us * 1e-6) / 1e12, peak=PEAK_F32_TFLOPS,
+                                                   unit='TFLOP/s', frac=gram_flops / (gram_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS,
+                                                   flop_per_launch=gram_flops, timer='HIP events around 50 launches (GEMM + finalise)',
+                                                   traffic=None)),
+               iteration_tflops=it_flops / (dt / iters) / 1e12)
+    if cpu_seconds > 0:
+        from oracle import audio_oracle as ao
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        feat = mag.cpu()[:, :F].contiguous()
+        gsr = ao.gram(smag.cpu()[:, :F].contiguous())
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < cpu_seconds:
+            ao.style_iterations(feat, gsr, 2, 1e-2)
+            k += 2
+        cdt = time.perf_counter() - t0
+        out['cpu_baseline'] = dict(value=k / cdt, unit='iters/s', cores=torch.get_num_threads(), kind='port',
+                                   sample=f'{k} iterations of the same optimisation through oracle/audio_oracle.py (torch CPU), {cdt:.1f} s')
+    return out
+
+
 LONG_CLIP = dict(C=8, R=151, T=4)       # BASELINE.json configs[4] mapped per SURVEY.md 8(d): 5 min at 120 bpm + 1 = 151 bars, 8 channels
+
+
+def long_clip_untiled(native, nat, dev, flat, iters, warm):
+    """The same long clip (C=8, R=151, T=4) as ONE untiled plan on one GPU, hipGraph-replayed: the denominator of the tiled
+    leg's strong-scaling efficiency (what one GPU does without any exchange)."""
+    from tools.synth import synth_clip
+    dims = nat.Dims(**LONG_CLIP, **WIDTHS, instr=51, n_instruments=41, has_unpitched=1)
+    plan = nat.Plan(native, dims, dev)
+    c = synth_clip(9, LONG_CLIP['C'], LONG_CLIP['R'], LONG_CLIP['T'], True)
+    plan.set_inputs(mode=c['mode'], bpm=c['bpm'], instr=c['instruments_features'], used=c['used_instruments'], bpm_target=float(c['bpm_int']))
+    xp, xu = c['pitched'].contiguous().to(dev), c['unpitched'].contiguous().to(dev)
+    params = flat.to(dev)
+    g, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+    state = torch.zeros(4, device=dev)
+    losses = torch.zeros(nat.N_LOSSES, device=dev)
+    P = nat.ptr
+    stream = torch.cuda.Stream(dev)
+
+    def iteration():
+        plan.train_iteration(params, g, xp, xu, losses)
+        nat.check(native.lib.mst_adam_step(P(params), P(g), P(m), P(v), params.numel(), P(state), .01, .9, .999, 1e-8, 200, .9, 1,
+                                           nat.current_stream(dev)), 'mst_adam_step')
+
+    with torch.cuda.stream(stream):
+        iteration()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            iteration()
+        for _ in range(warm):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(value=iters / dt, unit='iters/s', ms_per_step=dt / iters * 1e3, steps=iters, hip_graph=True,
+                final_total_loss=float(losses.cpu()[0]))
 
 
 def tiled_leg(native, nat, dev, flat, dist, rank, world, iters, warm):
@@ -369,7 +490,8 @@ def tiled_leg(native, nat, dev, flat, dist, rank, world, iters, warm):
                 config=dict(workload=f'one 5-min clip C={C_},R={R_},T={T_} (+percussion), bars tiled over {world} rank(s) '
                                      f'(BASELINE.json configs[4]): fwd+loss+bwd+Adam every step, {n_x[0] // max(iters, 1)} in-iteration '
                                      'all-reduces (SUM) of small workspace ranges + the flat-gradient all-reduce',
-                            bars_per_rank=rows, hip_graph=False, final_total_loss=float(losses.cpu()[0])))
+                            bars_per_rank=rows, hip_graph=False, collectives_per_iteration=n_x[0] // max(iters, 1) + (1 if dist is not None else 0),
+                            final_total_loss=float(losses.cpu()[0])))
 
 
 def main():
@@ -395,6 +517,9 @@ def main():
     ap.add_argument('--surface-steps', type=int, default=200,
                     help='with the default workload on 1 GPU: also time this many loop bodies through the nn.Module surface '
                          '(the drop-in path behind train-model.py) and report them as "surface"; 0 = skip')
+    ap.add_argument('--audio-steps', type=int, default=200,
+                    help='with the default workload on 1 GPU: also time this many iterations of the AUDIO EXTENSION (no reference '
+                         'counterpart; reported as "audio_extension", never part of the headline); 0 = skip')
     ap.add_argument('--tile-bars', action='store_true',
                     help='headline = BASELINE.json configs[4] instead: ONE long clip (C=8, R=151, T=4) with its bars tiled over the '
                          '--gpus ranks (strong scaling)')
@@ -431,6 +556,10 @@ def main():
     flat, table = init_params(native, dims1)
     if args.tile_bars:
         r = tiled_leg(native, nat, dev, flat, dist, rank, world, args.steps, args.warmup)
+        # the untiled clip on ONE GPU (every rank measures its own card; rank 0 reports): strong-scaling denominator
+        un = long_clip_untiled(native, nat, dev, flat, max(10, args.steps // 2), 3)
+        r['config']['untiled_one_gpu'] = un
+        r['config']['speedup_vs_untiled_one_gpu'] = r['value'] / un['value']
         if rank == 0:
             print(json.dumps(dict(metric='style-transfer opt iters/sec', value=r['value'], unit='iters/s', n_gpus=world, steps=args.steps,
                                   warmup=args.warmup, ms_per_step=r['ms_per_step'], higher_is_better=True, scaling='strong',
@@ -653,6 +782,11 @@ def main():
             out['batched'] = batched_leg(native, nat, dev, flat, args.batched_clips, args.batched_passes, 3)
         if world == 1 and B == 1 and not batched and args.surface_steps > 0:
             out['surface'] = surface_leg(dev, clip, args.surface_steps, 20)
+        if world == 1 and B == 1 and not batched and args.audio_steps > 0:
+            try:
+                out['audio_extension'] = audio_leg(nat, dev, args.audio_steps, 10, 0 if args.no_cpu_baseline else 4.0)
+            except Exception as e:                      # noqa: BLE001  (an extension must never take the headline line down)
+                out['audio_extension'] = dict(error=repr(e))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(flat, table, clip, args.cpu_seconds)
         print(json.dumps(out))

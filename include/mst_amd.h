@@ -164,15 +164,17 @@ int32_t mst_train_iteration(const mst_plan* p, const float* params, float* gpara
                             const float* pitched, const float* unpitched, float* losses, mst_stream stream);
 
 /* ---- one loop body (train-model.py:113-126) of a clip whose bars are tiled over ranks.  Every rank calls phase 0, 1, ...
- * mst_tiled_phase_count() - 1 on its own plan / workspace / gparams; after a phase that returns *xlen > 0 the host all-reduces
- * (SUM) ws[*xoff, *xoff + *xlen) over the ranks (torch.distributed / RCCL) before the next phase.  Afterwards gparams holds this
- * rank's share of the clip's gradient: all-reduce (SUM) it like in data parallelism (train-model.py:126,151-153), then
+ * mst_tiled_phase_count() - 1 on its own plan / workspace / gparams; a phase returns *nx <= MST_MAX_XCHG workspace ranges
+ * ws[xoff[q], xoff[q] + xlen[q]) that the host all-reduces (SUM) over the ranks before the next phase — as ONE collective (pack the
+ * ranges, reduce, unpack: Plan.tiled_train_iteration); exchanges of one dependency level end the same phase.  Afterwards gparams
+ * holds this rank's share of the clip's gradient: all-reduce (SUM) it like in data parallelism (train-model.py:126,151-153), then
  * mst_adam_step.  is_root: exactly one rank passes 1 (it contributes the replicated song-info loss gradients).  losses:
  * MST_N_LOSSES floats, identical on every rank. */
+#define MST_MAX_XCHG 8
 int32_t mst_tiled_phase_count(const mst_plan* p);
 int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float* params, float* gparams, float* ws,
                         const float* pitched, const float* unpitched, float* losses, int32_t is_root,
-                        mst_stream stream, int64_t* xoff, int64_t* xlen);
+                        mst_stream stream, int64_t xoff[MST_MAX_XCHG], int64_t xlen[MST_MAX_XCHG], int32_t* nx);
 
 /* ---- torch.optim.Adam(lr=.01) + StepLR(200,.9) + zero_grad (train-model.py:89-90,151-154)
  * over the flat buffers. state: 4 floats {step count t, lr_t/(1-b1^t), sqrt(1-b2^t), reserved} kept on the device so that

@@ -17,6 +17,7 @@
 // barrier per k-tile, 16-byte global loads along each operand's unit-stride direction, the next k-tile's loads in flight under the
 // current tile's 64 MFMAs per wave.  Edge 32 x 32 blocks that lie outside the matrix are skipped (bins = 513 = 16 x 32 + 1).
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "mst_common.h"
@@ -127,7 +128,10 @@ __global__ __launch_bounds__(256, 2) void ag_gemm_kernel(const AgGemm g) {
     constexpr int PA = AG_BM + (AKF ? 1 : 4), PB = AG_BN + (BKF ? 1 : 4);     // k-major row pitch: odd for transposing stores, 16-byte for b128
     __shared__ __attribute__((aligned(16))) float As[2][AG_KT][PA];
     __shared__ __attribute__((aligned(16))) float Bs[2][AG_KT][PB];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1, l31 = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    // the wave index as a SCALAR: everything derived from it (which 32 x 32 blocks are live) must be a uniform branch — as a
+    // per-lane value the compiler predicated every MFMA separately and shuttled the accumulators through one register set
+    const int wv = MST_UNIFORM(tid >> 6), wm = wv >> 1, wn = wv & 1;
     const int tiles_n = (g.N + AG_BN - 1) / AG_BN;
     const int tile = blockIdx.x % g.ntile, split = blockIdx.x / g.ntile;
     const int tm = g.tiles ? g.tiles[2 * tile] : tile / tiles_n, tn = g.tiles ? g.tiles[2 * tile + 1] : tile % tiles_n;
@@ -198,15 +202,32 @@ __global__ __launch_bounds__(256, 2) void ag_gemm_kernel(const AgGemm g) {
         }
         MST_LDS_BARRIER();                                  // (a wave past this barrier has finished reading the other buffer)
         if (kt + AG_KT < k1) issue(kt + AG_KT);            // flies under this k-tile's MFMAs and across the next barrier
+        // four code paths by which of the wave's 32 x 32 blocks exist (uniform, decided once per k-tile): no per-MFMA predicates
+        auto ktile = [&](auto LM1, auto LN1) {
 #pragma unroll
-        for (int s = 0; s < AG_KT / 2; ++s) {
-            const int k = 2 * s + kh;
-            const float a0 = As[buf][k][wm * 64 + l31], a1 = As[buf][k][wm * 64 + 32 + l31];
-            const float b0 = Bs[buf][k][wn * 64 + l31], b1 = Bs[buf][k][wn * 64 + 32 + l31];
-            if (lm[0] && ln[0]) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            if (lm[0] && ln[1]) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            if (lm[1] && ln[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            if (lm[1] && ln[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int s = 0; s < AG_KT / 2; ++s) {
+                const int k = 2 * s + kh;
+                const float a0 = As[buf][k][wm * 64 + l31], b0 = Bs[buf][k][wn * 64 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if constexpr (decltype(LN1)::value) {
+                    const float b1 = Bs[buf][k][wn * 64 + 32 + l31];
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    if constexpr (decltype(LM1)::value) {
+                        const float a1 = As[buf][k][wm * 64 + 32 + l31];
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+                } else if constexpr (decltype(LM1)::value) {
+                    const float a1 = As[buf][k][wm * 64 + 32 + l31];
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                }
+            }
+        };
+        if (lm[0] && ln[0]) {
+            if (lm[1] && ln[1]) ktile(std::true_type{}, std::true_type{});
+            else if (lm[1]) ktile(std::true_type{}, std::false_type{});
+            else if (ln[1]) ktile(std::false_type{}, std::true_type{});
+            else ktile(std::false_type{}, std::false_type{});
         }
         buf ^= 1;
     }

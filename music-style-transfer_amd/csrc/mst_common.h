@@ -16,6 +16,10 @@
 #ifndef MST_CONST_AS
 #define MST_CONST_AS __attribute__((address_space(4)))
 #endif
+// a value that is the same in every lane of the wave, as a scalar (SGPR): branches on it are uniform branches
+#ifndef MST_UNIFORM
+#define MST_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, then s_barrier.  Unlike
 // __syncthreads() it does not drain vmcnt, so global prefetches / streamed stores issued around
 // it stay in flight (on MI355X the vmcnt(0) of __syncthreads() cost ~1-4 us per LSTM step).

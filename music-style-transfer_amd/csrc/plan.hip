@@ -200,7 +200,7 @@ enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_
        // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
        K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG,
        K_GEMM_FOLD };      // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
-struct Step { int kind, first, count, a, b, stage; int c = 0; };      // c: GEMM steps — offset of the step's block -> member table
+struct Step { int kind, first, count, a, b, stage; int c = 0; int lvl = 0; };      // c: GEMM steps — offset of the step's block -> member table; lvl: dependency level in its scheduled pass
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
@@ -252,7 +252,9 @@ struct mst_plan {
     int64_t loss_sum_off = 0;                                               // [SP_TMP] 16 floats: the loss partial sums, folded
     int loss_fold[2] = {-1, -1};
     // one train iteration of a tiled plan as phases: each runs launch steps and ends at an exchange (or at the end)
-    struct Phase { int what; int pass; int begin, end; int xchg; };        // what: 0 schedule steps, 1 loss partials, 2 loss tail + seed
+    // what: 0 schedule steps, 1 loss partials, 2 loss tail + seed; xchg[0 .. nx): the exchanges the phase ends at — exchanges of
+    // one dependency level are MERGED into one phase end (what runs between them in the level-ordered list cannot depend on them)
+    struct Phase { int what; int pass; int begin, end; int nx; int xchg[MST_MAX_XCHG]; };
     std::vector<Phase> phases;
     int K() const { return d.clips > 1 ? d.clips : 1; }
     static int device_cus() {          // compute units of the current device (256 on MI355X in SPX mode)
@@ -1342,7 +1344,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             const Step& s0 = seq[i];
             const bool mergeable = !opt.no_merge && (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD || s0.kind == K_GATHER || s0.kind == K_SEGRED || s0.kind == K_LSTM_T ||
                                    s0.kind == K_LSTM_F || s0.kind == K_LSTM_B || s0.kind == K_COMB_F || s0.kind == K_COMB_B);
-            Step m = s0; m.count = 0;
+            Step m = s0; m.count = 0; m.lvl = lv;
             const bool is_lstm = s0.kind == K_LSTM_T || s0.kind == K_LSTM_F || s0.kind == K_LSTM_B;
             const bool is_comb = s0.kind == K_COMB_F || s0.kind == K_COMB_B || (s0.kind >= K_COMB_F1 && s0.kind <= K_COMB_B2);
             const bool is_notes = s0.kind == K_ME_F || s0.kind == K_ME_B || s0.kind == K_PSA_F || s0.kind == K_PSA_B || s0.kind == K_ME_SQ || s0.kind == K_ME_RED;
@@ -1536,18 +1538,44 @@ void mst_plan::schedule() {
         f.part_off = loss_scratch + (mst_loss_scratch_floats() - 64) / 2; f.nrows = U ? loss_blocks(nu) : 1; f.sum_off = loss_sum_off + 8;
         loss_fold[1] = (int)folds.size(); folds.push_back(f);
     }
+    auto mk = [](int what, int pass, int begin, int end) { Phase ph{}; ph.what = what; ph.pass = pass; ph.begin = begin; ph.end = end; ph.nx = 0; return ph; };
+    // An exchange is DEFERRED past every following step that does not touch its range (the list is a valid order, and such a step
+    // cannot depend on what the exchange delivers): it joins the group of pending exchanges, and the phase is cut only in front of
+    // the first step that reads or writes a pending range — all pending exchanges then travel as one collective.  13 ranges per
+    // iteration become the number of true dependency points between exchanged data and its consumers.
     auto split = [&](int pass) {
         const std::vector<Step>& L = sched_all[pass];
         int begin = 0;
-        for (int i = 0; i < (int)L.size(); ++i)
-            if (L[i].kind == K_XCHG) { phases.push_back(Phase{0, pass, begin, i, L[i].first}); begin = i + 1; }
-        phases.push_back(Phase{0, pass, begin, (int)L.size(), -1});
+        Phase cur = mk(0, pass, 0, 0);
+        auto touches_pending = [&](const Step& st) {
+            if (!cur.nx) return false;
+            std::vector<Acc> acc;
+            const bool plain = st.kind >= K_COPY_F && st.kind != K_GEMM_FOLD;
+            accesses(st, acc, !plain);
+            for (int q = 0; q < cur.nx; ++q) {
+                const Xchg& x = xchgs[cur.xchg[q]];
+                for (const Acc& a : acc)
+                    if (a.space == x.space && a.lo < x.off + x.len && x.off < a.hi) return true;
+            }
+            return false;
+        };
+        for (int i = 0; i < (int)L.size(); ++i) {
+            const bool is_x = L[i].kind == K_XCHG;
+            if ((is_x && cur.nx == MST_MAX_XCHG) || (!is_x && touches_pending(L[i]))) {
+                cur.begin = begin; cur.end = i;          // steps [begin, i) run (exchange steps among them are skipped), then the exchanges
+                phases.push_back(cur);
+                begin = i; cur = mk(0, pass, 0, 0);
+            }
+            if (is_x) cur.xchg[cur.nx++] = L[i].first;
+        }
+        cur.begin = begin; cur.end = (int)L.size();
+        phases.push_back(cur);                            // (a trailing group of exchanges, if any, is delivered after the last step)
     };
     split(0);
     const int lx = (int)xchgs.size();
     xchgs.push_back(Xchg{SP_TMP, loss_sum_off, 16});
-    phases.push_back(Phase{1, 0, 0, 0, lx});
-    phases.push_back(Phase{2, 0, 0, 0, -1});
+    { Phase ph = mk(1, 0, 0, 0); ph.nx = 1; ph.xchg[0] = lx; phases.push_back(ph); }
+    phases.push_back(mk(2, 0, 0, 0));
     split(1);
 }
 
@@ -1854,8 +1882,8 @@ extern "C" int32_t mst_tiled_phase_count(const mst_plan* p) { return p ? (int32_
 
 extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float* params, float* gparams, float* ws,
                                    const float* pitched, const float* unpitched, float* losses, int32_t is_root,
-                                   mst_stream stream, int64_t* xoff, int64_t* xlen) {
-    if (!p || !p->tiled() || phase < 0 || phase >= (int)p->phases.size() || !params || !gparams || !ws || !pitched || !xoff || !xlen)
+                                   mst_stream stream, int64_t* xoff, int64_t* xlen, int32_t* nx) {
+    if (!p || !p->tiled() || phase < 0 || phase >= (int)p->phases.size() || !params || !gparams || !ws || !pitched || !xoff || !xlen || !nx)
         return MST_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const mst_plan::Phase& ph = p->phases[phase];
@@ -1872,6 +1900,7 @@ extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float
     if (ph.what == 0) {
         const std::vector<Step>& L = p->sched_all[ph.pass];
         for (int i = ph.begin; i < ph.end; ++i) {
+            if (L[i].kind == K_XCHG) continue;          // an earlier exchange of the level this phase ends at: delivered with the others
             int e = run_step(p, L[i], b, st);
             if (e) return e < 0 ? e : MST_ERR_LAUNCH;
         }
@@ -1897,11 +1926,11 @@ extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float
                              lb, st, is_root ? 1.f : 0.f);
         if (e) return e;
     }
-    *xoff = 0; *xlen = 0;
-    if (ph.xchg >= 0) {
-        const mst_plan::Xchg& x = p->xchgs[ph.xchg];
+    *nx = ph.nx;
+    for (int q = 0; q < ph.nx; ++q) {
+        const mst_plan::Xchg& x = p->xchgs[ph.xchg[q]];
         const int64_t base = x.space == SP_WS ? 0 : (x.space == SP_GRAD ? p->act_top : 2 * p->act_top);
-        *xoff = base + x.off; *xlen = x.len;
+        xoff[q] = base + x.off; xlen[q] = x.len;
     }
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }

@@ -96,7 +96,8 @@ _SIGS = {
                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     'mst_train_iteration': (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'mst_tiled_phase_count': (C.c_int32, [_P]),
-    'mst_tiled_phase': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'mst_tiled_phase': (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int64 * 8), C.POINTER(C.c_int64 * 8),
+                        C.POINTER(C.c_int32)]),
     'mst_adam_step': (C.c_int32, [_P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_int32, C.c_double, C.c_int32, _P]),
     'mst_adam_step2': (C.c_int32, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -320,14 +321,27 @@ class Plan:
         if all_reduce is None:
             import torch.distributed as dist
             all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        xoff, xlen = C.c_int64(), C.c_int64()
+        xoff, xlen, nx = (C.c_int64 * 8)(), (C.c_int64 * 8)(), C.c_int32()
         self._touch(None)
         for ph in range(self.lib.mst_tiled_phase_count(self.handle)):
             check(self.lib.mst_tiled_phase(self.handle, ph, ptr(params), ptr(gparams), ptr(self.ws), ptr(pitched), ptr(unpitched),
-                                           ptr(losses), int(bool(is_root)), current_stream(self.device), C.byref(xoff), C.byref(xlen)),
-                  f'mst_tiled_phase({ph})')
-            if xlen.value:
-                all_reduce(self.ws[xoff.value:xoff.value + xlen.value])
+                                           ptr(losses), int(bool(is_root)), current_stream(self.device), C.byref(xoff), C.byref(xlen),
+                                           C.byref(nx)), f'mst_tiled_phase({ph})')
+            if nx.value == 1:
+                all_reduce(self.ws[xoff[0]:xoff[0] + xlen[0]])
+            elif nx.value > 1:
+                # the exchanges of one dependency level travel as ONE collective: pack, reduce, unpack
+                parts = [self.ws[xoff[q]:xoff[q] + xlen[q]] for q in range(nx.value)]
+                total = sum(int(xlen[q]) for q in range(nx.value))
+                if getattr(self, '_xstage', None) is None or self._xstage.numel() < total:
+                    self._xstage = torch.empty(total, dtype=torch.float32, device=self.device)
+                stage = self._xstage[:total]
+                torch.cat(parts, out=stage)
+                all_reduce(stage)
+                at = 0
+                for t in parts:
+                    t.copy_(stage[at:at + t.numel()])
+                    at += t.numel()
 
     def train_iteration(self, params, gparams, pitched, unpitched, losses=None, ws=None):
         check(self.lib.mst_train_iteration(self.handle, ptr(params), ptr(gparams), ptr(self._touch(ws)),

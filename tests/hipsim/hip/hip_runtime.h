@@ -41,6 +41,7 @@ extern "C" void __sanitizer_finish_switch_fiber(void*, const void**, size_t*);
 #define HIPSIM 1
 #define MST_GLOBAL_AS
 #define MST_CONST_AS
+#define MST_UNIFORM(x) (x)
 #define MST_LDS_BARRIER() __syncthreads()
 #define MST_FAST_EXP(x) expf(x)
 #define MST_FAST_RCP(x) (1.f / (x))

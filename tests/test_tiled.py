@@ -32,22 +32,24 @@ def run_tiled(native, device, widths, Cn, R, T, unp, tiles, clip, flat, poison=T
         xu.append(clip['unpitched'][:, :, r0:r0 + rows].contiguous().to(device) if unp else None)
     n = native.lib.mst_tiled_phase_count(plans[0].handle)
     assert n > 3 and all(native.lib.mst_tiled_phase_count(p.handle) == n for p in plans)
-    xoff, xlen = C.c_int64(), C.c_int64()
+    xoff, xlen, nx = (C.c_int64 * 8)(), (C.c_int64 * 8)(), C.c_int32()
     n_exchanges = 0
     for ph in range(n):
         spans = []
         for k, p in enumerate(plans):
             nat.check(native.lib.mst_tiled_phase(p.handle, ph, nat.ptr(params), nat.ptr(grads[k]), nat.ptr(p.ws), nat.ptr(xp[k]),
                                                  nat.ptr(xu[k]), nat.ptr(losses[k]), int(k == 0), nat.current_stream(device),
-                                                 C.byref(xoff), C.byref(xlen)), 'mst_tiled_phase')
-            spans.append((xoff.value, xlen.value))
-        assert len(set(ln for _, ln in spans)) == 1, spans     # every rank exchanges the same buffer (its offset may differ
-        ln = spans[0][1]                                        # with the tile size: each workspace has its own layout)
-        if ln:
-            n_exchanges += 1
-            total = sum(p.ws[off:off + ln] for p, (off, _) in zip(plans, spans))
-            for p, (off, _) in zip(plans, spans):
-                p.ws[off:off + ln] = total
+                                                 C.byref(xoff), C.byref(xlen), C.byref(nx)), 'mst_tiled_phase')
+            spans.append([(xoff[q], xlen[q]) for q in range(nx.value)])
+        # every rank exchanges the same buffers (their offsets may differ with the tile size: each workspace has its own layout)
+        assert len(set(tuple(ln for _, ln in sp) for sp in spans)) == 1, spans
+        if spans[0]:
+            n_exchanges += 1                                    # the ranges of one phase end travel as one collective
+        for q in range(len(spans[0])):
+            ln = spans[0][q][1]
+            total = sum(p.ws[sp[q][0]:sp[q][0] + ln] for p, sp in zip(plans, spans))
+            for p, sp in zip(plans, spans):
+                p.ws[sp[q][0]:sp[q][0] + ln] = total
     return sum(grads), losses, plans, n_exchanges
 
 
@@ -82,7 +84,8 @@ def test_tiled_clip_equals_one_rank_plan_and_oracle(tiles):
     for i, k in enumerate(nat.LOSS_KEYS):
         if k in ref_losses:
             assert abs(float(lt[0][i]) - ref_losses[k]) < 5e-5, k
-    assert nx <= 16
+    print("collectives per tiled iteration:", nx)
+    assert nx <= 10         # 13 exchanged ranges travel as 10 collectives: an exchange is deferred until its first consumer
 
 
 def test_tiled_pitched_only_single_tile_is_the_whole_clip():

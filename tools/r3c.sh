@@ -12,5 +12,7 @@ d = json.loads(open('gpurun_out/${T}_bench.json').read().strip().splitlines()[-1
 b = d.get('batched') or {}
 print('one clip: %.0f it/s %.3f ms upload %s launches %s' % (d['value'], d['ms_per_step'], d.get('value_with_upload'), d['config'].get('launches_per_pass')))
 print('surface', (d.get('surface') or {}).get('value'), (d.get('surface') or {}).get('fused_value'))
+ae = d.get("audio_extension") or {}
+print("audio ext", ae.get("value"), ae.get("stft"), ae.get("gram"), ae.get("error"))
 if b: print('batched: %.0f clip-it/s, %.2f ms/pass' % (b['value'], b['ms_per_pass']))
 PY
