@@ -365,50 +365,134 @@ class StyleTransferModel(nn.Module):
     def train_iteration(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels, used_instruments, bpm_target):
         """Opt-in fast form of one train-model.py loop body (train-model.py:113-126): forward, get_total_loss(normalize=True)
         with the inputs as targets, and loss.backward() in ONE C-ABI call (mst_train_iteration) — no autograd graph, no
-        per-stage Python.  Gradients accumulate into the same flat buffer p.grad aliases, so optimizer.step() follows as
-        usual.  Returns the 15 loss leaves as one device tensor (key order style._native.LOSS_KEYS)."""
+        per-stage Python.  Gradients accumulate (sum) for optimizer.step() as usual.  Returns the 15 loss leaves as one device
+        tensor (key order style._native.LOSS_KEYS; a row of a ring, valid for the next 256 calls of its lane).
+
+        With `concurrent_accumulation` (FusedAdam switches it on) consecutive calls alternate between two LANES — two side
+        streams, two workspaces per plan, two gradient buffers — so the iter_size = 2 accumulation iterations between two
+        optimizer steps (train-model.py:95,151-153; they are independent: same parameters, gradients summed) overlap on the
+        device; FusedAdam.step() joins the lanes and applies Adam to the sum of the two buffers (mst_adam_step2: bitwise what
+        in-place accumulation gives).  p.grad shows lane 0's share until then."""
         anchor = self._anchor()
         dev = anchor.device
         pitched = _f32c(pitched_channels, dev)
         unpitched = None if unpitched_channels is None else _f32c(unpitched_channels, dev)
         _, C, R, T = pitched.shape[:4]
         plan = self._plan(C, R, T, unpitched is not None, dev)
-        plan.set_inputs(mode=_f32c(mode, dev), bpm=_f32c(bpm, dev), instr=_f32c(instruments_features, dev),
-                        used=_f32c(used_instruments, dev), bpm_target=torch.as_tensor(float(bpm_target), dtype=torch.float32))
-        gflat = self._grad_target()
-        # A shape seen before replays a hipGraph of the whole loop body (the launches of mst_train_iteration captured once
-        # per plan over static input buffers); songs of a new shape run eagerly.  The graph is keyed by the buffers it baked in.
-        key = (self._flat.data_ptr(), gflat.data_ptr())
-        g = plan.graph if getattr(plan, 'graph_key', None) == key else None
-        if g is None and getattr(plan, 'uses', 0) >= 1 and dev.type == 'cuda' and getattr(self, 'graph_repeated_shapes', True):
-            # (the plan has run eagerly before, so its code objects are loaded: capturing executes nothing and needs no warm-up)
-            st = plan.static = dict(pitched=torch.empty_like(pitched), unpitched=None if unpitched is None else torch.empty_like(unpitched),
-                                    losses=torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev))
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                plan.train_iteration(self._flat, gflat, st['pitched'], st['unpitched'], st['losses'])
-            plan.graph, plan.graph_key = g, key
-        plan.uses = getattr(plan, 'uses', 0) + 1
-        if g is not None:
-            st = plan.static
-            plan._touch(None)                        # a replay launches on the plan's own workspace
-            st['pitched'].copy_(pitched)
-            if unpitched is not None:
-                st['unpitched'].copy_(unpitched)
-            g.replay()
+        lanes = self._lanes(dev)
+        li = 0
+        if getattr(self, 'concurrent_accumulation', False):
+            li = self._lane_next
+            self._lane_next ^= 1
+        lane = lanes[li]
+        gflat = self._grad_target() if li == 0 else lane['grad']
+        st = plan.__dict__.setdefault('_lane_state', {}).get(li)
+        if st is None:
+            st = plan._lane_state[li] = dict(ws=plan.ws if li == 0 else plan.new_ws(), graph=None, key=None, uses=0,
+                                             pitched=torch.empty_like(pitched), unpitched=None if unpitched is None else torch.empty_like(unpitched),
+                                             losses=torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev))
+        ws = st['ws']
+        small = [_f32c(mode, dev).reshape(-1), _f32c(bpm, dev).reshape(-1), _f32c(instruments_features, dev).reshape(-1),
+                 _f32c(used_instruments, dev).reshape(-1),
+                 torch.as_tensor(float(bpm_target), dtype=torch.float32).reshape(1).to(dev, non_blocking=True)]
+        slots = [plan.view(n, ws=ws) for n in ('mode', 'bpm', 'instr', 'used_instruments', 'bpm_target')]
+        cur = torch.cuda.current_stream(dev)
+        side = lane['stream'] if li or getattr(self, 'concurrent_accumulation', False) else cur
+        if side is not cur:
+            side.wait_stream(cur)                      # the caller's inputs (and the last optimizer step) are ready
+            for t in small + [pitched] + ([unpitched] if unpitched is not None else []):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            # the note tensors are copied into the lane's static buffers unless the caller already wrote them there
+            # (static_inputs()): a captured graph reads fixed addresses
+            srcs, dsts = list(small), list(slots)
+            if pitched.data_ptr() != st['pitched'].data_ptr():
+                srcs.append(pitched.reshape(-1)); dsts.append(st['pitched'].reshape(-1))
+            if unpitched is not None and unpitched.data_ptr() != st['unpitched'].data_ptr():
+                srcs.append(unpitched.reshape(-1)); dsts.append(st['unpitched'].reshape(-1))
+            torch._foreach_copy_(dsts, srcs)           # one launch for all of them
+            # A shape seen before replays a hipGraph of the whole loop body (the launches of mst_train_iteration captured once
+            # per plan and lane over static input buffers); songs of a new shape run eagerly.  Keyed by the buffers it baked in.
+            key = (self._flat.data_ptr(), gflat.data_ptr())
+            g = st['graph'] if st['key'] == key else None
+            if g is None and st['uses'] >= 1 and dev.type == 'cuda' and getattr(self, 'graph_repeated_shapes', True):
+                # (the plan has run eagerly before, so its code objects are loaded: capturing executes nothing and needs no warm-up)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side if side is not cur else None):
+                    plan.train_iteration(self._flat, gflat, st['pitched'], st['unpitched'], st['losses'], ws=ws)
+                st['graph'], st['key'] = g, key
+            st['uses'] += 1
+            if g is not None:
+                plan._touch(ws)                         # a replay launches on this workspace
+                g.replay()
+            else:
+                plan.train_iteration(self._flat, gflat, st['pitched'], st['unpitched'], st['losses'], ws=ws)
+            ring = lane['ring']
+            row = ring[lane['at'] % ring.shape[0]]
+            lane['at'] += 1
+            row.copy_(st['losses'])
+        lane['dirty'] = True
+        if li == 0:
             self._publish_grads()
-            return st['losses'].clone()
-        losses = torch.empty(_native.N_LOSSES, dtype=torch.float32, device=dev)
-        plan.train_iteration(self._flat, gflat, pitched, unpitched, losses)
-        self._publish_grads()
-        return losses
+        return row
+
+    def static_inputs(self, C, R, T, unpitched=True, lane=0):
+        """The note-tensor buffers a captured train_iteration of this shape reads (created on first use by train_iteration): a
+        loader that writes its H2D copies straight into them saves the per-iteration device copy."""
+        plan = self._plan(C, R, T, unpitched, self._anchor().device)
+        st = plan.__dict__.get('_lane_state', {}).get(lane)
+        return (st['pitched'], st['unpitched']) if st else None
+
+    def _lanes(self, dev):
+        lanes = self.__dict__.get('_lane_list')
+        if lanes is None or lanes[0]['ring'].device != dev:
+            mk = lambda: dict(stream=torch.cuda.Stream(dev) if dev.type == 'cuda' else None, grad=None, dirty=False, at=0,
+                              ring=torch.zeros(256, _native.N_LOSSES, dtype=torch.float32, device=dev))
+            lanes = self.__dict__['_lane_list'] = [mk(), mk()]
+            lanes[1]['grad'] = torch.zeros_like(self._flat)
+            self.__dict__['_lane_next'] = 0
+        if lanes[1]['grad'].data_ptr() == 0 or lanes[1]['grad'].numel() != self._flat.numel() or lanes[1]['grad'].device != self._flat.device:
+            lanes[1]['grad'] = torch.zeros_like(self._flat)
+        return lanes
+
+    def join_lanes(self):
+        """Make the current stream wait for everything train_iteration has enqueued on its lanes; returns lane 1's gradient
+        buffer if it holds a share of the accumulated gradient (else None).  FusedAdam.step and LossLog.flush call it."""
+        lanes = self.__dict__.get('_lane_list')
+        if not lanes:
+            return None
+        cur = torch.cuda.current_stream(lanes[0]['ring'].device)
+        for lane in lanes:
+            if lane['dirty'] and lane['stream'] is not None:
+                cur.wait_stream(lane['stream'])
+        second = lanes[1]['grad'] if lanes[1]['dirty'] else None
+        for lane in lanes:
+            lane['dirty'] = False
+        self.__dict__['_lane_next'] = 0
+        return second
+
+    def __getstate__(self):                          # lane streams / rings / graphs are run-time state, never pickled
+        d = dict(self.__dict__)
+        for k in ('_lane_list', '_lane_next'):
+            d.pop(k, None)
+        return d
 
     def check_device_status(self):
         """Raise MstError if a kernel reported a device-side failure (include/mst_amd.h MST_DEV_*: the multi-workgroup LSTM's
         exchange timing out) on any workspace used since the last check.  Synchronises; call it where the loop reads its
         losses back anyway (style.train.LossLog.flush does)."""
+        self.join_lanes_keep()
         for plan in list(_native.get()._plans.values()):
             plan.check_touched()
+
+    def join_lanes_keep(self):
+        """Wait for the lanes without consuming their gradient bookkeeping (a health check is not an optimizer step)."""
+        lanes = self.__dict__.get('_lane_list')
+        if lanes:
+            cur = torch.cuda.current_stream(lanes[0]['ring'].device)
+            for lane in lanes:
+                if lane['dirty'] and lane['stream'] is not None:
+                    cur.wait_stream(lane['stream'])
 
     def forward(self, mode, bpm, pitched_channels, instruments_features, unpitched_channels=None):
         ip, mp, bp, xp, xu = _Forward.apply(self, self._anchor(), torch.is_grad_enabled(), mode, bpm, pitched_channels,

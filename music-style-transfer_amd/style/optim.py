@@ -21,6 +21,9 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(model._flat)
         self.state = torch.zeros(4, dtype=torch.float32, device=model._flat.device)
         self.process_group = process_group
+        # consecutive StyleTransferModel.train_iteration calls may now overlap on two lanes (two gradient buffers): this
+        # optimizer joins them in step()
+        model.concurrent_accumulation = True
 
     def all_reduce_grads(self):
         if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -30,13 +33,28 @@ class FusedAdam:
     def step(self, zero_grad=True):
         m = self.model
         m._sync_flat()
+        g2 = m.join_lanes() if hasattr(m, 'join_lanes') else None
+        if g2 is not None and (self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                                  and torch.distributed.get_world_size() > 1)):
+            m._gflat.add_(g2); g2.zero_(); g2 = None          # one buffer for the collective
         self.all_reduce_grads()
         n = m._flat.numel()
         P = _native.ptr
+        if g2 is not None:
+            _native.check(_native.get().lib.mst_adam_step2(P(m._flat), P(m._gflat), P(g2), P(self.exp_avg), P(self.exp_avg_sq), n,
+                                                           P(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                           self.step_size, self.gamma, int(zero_grad),
+                                                           _native.current_stream(m._flat.device)), 'mst_adam_step2')
+            if not zero_grad:
+                m._gflat.add_(g2); g2.zero_()                 # keep the accumulated sum visible in p.grad
+            return
         _native.check(_native.get().lib.mst_adam_step(P(m._flat), P(m._gflat), P(self.exp_avg), P(self.exp_avg_sq), n,
                                                       P(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
                                                       self.step_size, self.gamma, int(zero_grad),
                                                       _native.current_stream(m._flat.device)), 'mst_adam_step')
 
     def zero_grad(self):
+        g2 = self.model.join_lanes() if hasattr(self.model, 'join_lanes') else None
+        if g2 is not None:
+            g2.zero_()
         self.model._gflat.zero_()

@@ -75,9 +75,9 @@ class LossLog:
     def flush(self):
         if not self.pending:
             return
-        values = torch.stack([p for _, p in self.pending]).cpu().numpy()          # the one D2H copy
         if self.health is not None:
-            self.health()             # a kernel-reported failure names itself here, before the NaN assert below would
+            self.health()             # joins the model's accumulation lanes; a kernel-reported failure names itself here
+        values = torch.stack([p for _, p in self.pending]).cpu().numpy()          # the one D2H copy
         rows = []
         for (iteration, _), v in zip(self.pending, values):
             leaf = dict(zip(_native.LOSS_KEYS, v.tolist()))
