@@ -180,57 +180,61 @@ __global__ __launch_bounds__(256, 2) void ag_gemm_kernel(const AgGemm g) {
             }
         }
     };
-    if (k0 < k1) issue(k0);
-    int buf = 0;
-    for (int kt = k0; kt < k1; kt += AG_KT) {
+    // The whole k-loop exists once per pattern of live 32 x 32 blocks of the wave (uniform: chosen once, outside the loop — inside
+    // it the compiler merged the paths' accumulators through register copies at every k-tile).  Every path runs the same loads
+    // and the same barriers; a wave without any live block only helps to stage the tiles.
+    auto run = [&](auto LM0, auto LM1, auto LN1) {
+        if (k0 < k1) issue(k0);
+        int buf = 0;
+        for (int kt = k0; kt < k1; kt += AG_KT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (AKF) {
+            for (int q = 0; q < 4; ++q) {
+                if (AKF) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) As[buf][4 * (tid & 7) + j][(tid >> 3) + 32 * q] = ra[q][j];
-            } else {
-                float* dst = &As[buf][(tid >> 5) + 8 * q][4 * (tid & 31)];
-                dst[0] = ra[q][0]; dst[1] = ra[q][1]; dst[2] = ra[q][2]; dst[3] = ra[q][3];
-            }
-            if (BKF) {
+                    for (int j = 0; j < 4; ++j) As[buf][4 * (tid & 7) + j][(tid >> 3) + 32 * q] = ra[q][j];
+                } else {
+                    float* dst = &As[buf][(tid >> 5) + 8 * q][4 * (tid & 31)];
+                    dst[0] = ra[q][0]; dst[1] = ra[q][1]; dst[2] = ra[q][2]; dst[3] = ra[q][3];
+                }
+                if (BKF) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[buf][4 * (tid & 7) + j][(tid >> 3) + 32 * q] = rb[q][j];
-            } else {
-                float* dst = &Bs[buf][(tid >> 5) + 8 * q][4 * (tid & 31)];
-                dst[0] = rb[q][0]; dst[1] = rb[q][1]; dst[2] = rb[q][2]; dst[3] = rb[q][3];
-            }
-        }
-        MST_LDS_BARRIER();                                  // (a wave past this barrier has finished reading the other buffer)
-        if (kt + AG_KT < k1) issue(kt + AG_KT);            // flies under this k-tile's MFMAs and across the next barrier
-        // four code paths by which of the wave's 32 x 32 blocks exist (uniform, decided once per k-tile): no per-MFMA predicates
-        auto ktile = [&](auto LM1, auto LN1) {
-#pragma unroll
-            for (int s = 0; s < AG_KT / 2; ++s) {
-                const int k = 2 * s + kh;
-                const float a0 = As[buf][k][wm * 64 + l31], b0 = Bs[buf][k][wn * 64 + l31];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                if constexpr (decltype(LN1)::value) {
-                    const float b1 = Bs[buf][k][wn * 64 + 32 + l31];
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    if constexpr (decltype(LM1)::value) {
-                        const float a1 = As[buf][k][wm * 64 + 32 + l31];
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                    }
-                } else if constexpr (decltype(LM1)::value) {
-                    const float a1 = As[buf][k][wm * 64 + 32 + l31];
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) Bs[buf][4 * (tid & 7) + j][(tid >> 3) + 32 * q] = rb[q][j];
+                } else {
+                    float* dst = &Bs[buf][(tid >> 5) + 8 * q][4 * (tid & 31)];
+                    dst[0] = rb[q][0]; dst[1] = rb[q][1]; dst[2] = rb[q][2]; dst[3] = rb[q][3];
                 }
             }
-        };
-        if (lm[0] && ln[0]) {
-            if (lm[1] && ln[1]) ktile(std::true_type{}, std::true_type{});
-            else if (lm[1]) ktile(std::true_type{}, std::false_type{});
-            else if (ln[1]) ktile(std::false_type{}, std::true_type{});
-            else ktile(std::false_type{}, std::false_type{});
+            MST_LDS_BARRIER();                              // (a wave past this barrier has finished reading the other buffer)
+            if (kt + AG_KT < k1) issue(kt + AG_KT);        // flies under this k-tile's MFMAs and across the next barrier
+            if constexpr (decltype(LM0)::value) {
+#pragma unroll
+                for (int s = 0; s < AG_KT / 2; ++s) {
+                    const int k = 2 * s + kh;
+                    const float a0 = As[buf][k][wm * 64 + l31], b0 = Bs[buf][k][wn * 64 + l31];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    if constexpr (decltype(LN1)::value) {
+                        const float b1 = Bs[buf][k][wn * 64 + 32 + l31];
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                        if constexpr (decltype(LM1)::value) {
+                            const float a1 = As[buf][k][wm * 64 + 32 + l31];
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                        }
+                    } else if constexpr (decltype(LM1)::value) {
+                        const float a1 = As[buf][k][wm * 64 + 32 + l31];
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    }
+                }
+            }
+            buf ^= 1;
         }
-        buf ^= 1;
-    }
+    };
+    typedef std::true_type Y; typedef std::false_type NO;
+    if (!(lm[0] && ln[0])) run(NO{}, NO{}, NO{});
+    else if (lm[1] && ln[1]) run(Y{}, Y{}, Y{});
+    else if (lm[1]) run(Y{}, Y{}, NO{});
+    else if (ln[1]) run(Y{}, NO{}, Y{});
+    else run(Y{}, NO{}, NO{});
     float* C = g.C + (g.ksplit > 1 ? (int64_t)split * g.slab_stride : 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -255,14 +259,24 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
     __shared__ float red[4];
     float sq = 0.f;
     const int total = ld * ld;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int e = blockIdx.x * 256 + threadIdx.x;           // one element per lane: ceil(ld^2 / 256) workgroups
+    if (e < total) {
         const int i = e / ld, j = e - i * ld;
         float gv = 0.f, dv = 0.f;
         if (i < nb && j < nb) {
             const int a = i >= j ? i : j, c = i >= j ? j : i;      // the stored (lower) element
-            for (int s = 0; s < splits; ++s) gv += slabs[(int64_t)s * slab_stride + (int64_t)a * ld + c];
+            const MST_GLOBAL_AS float* src = (const MST_GLOBAL_AS float*)slabs + ((int64_t)a * ld + c);
+            int s = 0;
+            for (; s + 8 <= splits; s += 8) {              // eight slab loads in flight, added in split order
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(s + q) * slab_stride];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gv += v[q];
+            }
+            for (; s < splits; ++s) gv += src[(int64_t)s * slab_stride];
             gv *= inv_t;
-            if (gs) { const float df = gv - gs[e]; dv = cd * df; sq += df * df; }
+            if (gs) { const float df = gv - gs[e]; dv = cd * df; sq = df * df; }
         }
         if (G) G[e] = gv;
         if (D) D[e] = dv;
@@ -274,16 +288,18 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
     if (threadIdx.x == 0 && loss_part) loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(64) void loss_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+__global__ __launch_bounds__(256) void loss_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+    __shared__ float red[4];
     float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += 64) a += part[i];
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (threadIdx.x == 0) loss[0] = a;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-#define AG_FIN_BLOCKS 256
 
 extern "C" mst_audio_plan* mst_audio_plan_create(int32_t n_fft, int32_t hop, int64_t n_samples, int32_t* status) {
     int32_t dummy; if (!status) status = &dummy;
@@ -297,9 +313,11 @@ extern "C" mst_audio_plan* mst_audio_plan_create(int32_t n_fft, int32_t hop, int
     std::vector<int> tiles;
     for (int i = 0; i < nt; ++i) for (int j = 0; j <= i; ++j) { tiles.push_back(i); tiles.push_back(j); }
     p->ntile = (int)tiles.size() / 2;
-    // k-splits of the Gram: enough workgroups for the chip twice over, at least 8 k-tiles each
-    int s = (512 + p->ntile - 1) / p->ntile;
-    const int maxs = (p->frames + 8 * AG_KT - 1) / (8 * AG_KT);
+    // k-splits of the Gram: the FULL lower-triangle tiles (both tile edges inside the matrix: bins = 513 leaves a fifth tile row of
+    // one live bin, whose workgroups are light) times the splits should fill the chip's 256 CUs once, with >= 4 k-tiles per split
+    const int nfull_edge = p->bins / AG_BM, nfull = nfull_edge * (nfull_edge + 1) / 2;
+    int s = nfull > 0 ? 256 / nfull : 256;
+    const int maxs = (p->frames + 4 * AG_KT - 1) / (4 * AG_KT);
     p->splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     {   // a split's share is rounded to whole k-tiles inside the kernel: no split may come out empty (its slab would stay unwritten)
         const int chunk = ((p->frames + p->splits - 1) / p->splits + AG_KT - 1) / AG_KT * AG_KT;
@@ -332,7 +350,7 @@ extern "C" int32_t mst_audio_plan_info(const mst_audio_plan* p, int64_t out[6]) 
     if (!p || !out) return MST_ERR_ARG;
     out[0] = p->frames; out[1] = p->bins; out[2] = p->ld;
     // workspace floats of mst_audio_gram / mst_audio_style_iteration: the Gram's k-split slabs, D, the loss partials
-    out[3] = (int64_t)p->splits * p->ld * p->ld + (int64_t)p->ld * p->ld + AG_FIN_BLOCKS + 64;
+    out[3] = (int64_t)p->splits * p->ld * p->ld + (int64_t)p->ld * p->ld + ((int64_t)p->ld * p->ld + 255) / 256 + 64;
     out[4] = p->splits; out[5] = p->ntile;
     return MST_OK;
 }
@@ -364,8 +382,8 @@ extern "C" int32_t mst_audio_gram(const mst_audio_plan* p, const float* feat, fl
     if (!p || !feat || !gram || !ws) return MST_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (gram_slabs(p, feat, ws, s)) return MST_ERR_LAUNCH;
-    hipLaunchKernelGGL(gram_finalize_kernel, dim3(AG_FIN_BLOCKS), dim3(256), 0, s, (const float*)ws, p->splits, (int64_t)p->ld * p->ld, p->bins,
-                       p->ld, 1.f / (float)p->frames, (const float*)nullptr, 0.f, gram, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(gram_finalize_kernel, dim3((p->ld * p->ld + 255) / 256), dim3(256), 0, s, (const float*)ws, p->splits, (int64_t)p->ld * p->ld,
+                       p->bins, p->ld, 1.f / (float)p->frames, (const float*)nullptr, 0.f, gram, (float*)nullptr, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? MST_OK : MST_ERR_LAUNCH;
 }
 
@@ -377,9 +395,10 @@ extern "C" int32_t mst_audio_style_iteration(const mst_audio_plan* p, float* x, 
     float* D = ws + (int64_t)p->splits * ll;
     float* part = D + ll;
     if (gram_slabs(p, x, ws, s)) return MST_ERR_LAUNCH;
-    hipLaunchKernelGGL(gram_finalize_kernel, dim3(AG_FIN_BLOCKS), dim3(256), 0, s, (const float*)ws, p->splits, ll, p->bins, p->ld,
+    const int fin_blocks = (int)((ll + 255) / 256);
+    hipLaunchKernelGGL(gram_finalize_kernel, dim3(fin_blocks), dim3(256), 0, s, (const float*)ws, p->splits, ll, p->bins, p->ld,
                        1.f / (float)p->frames, gram_style, 4.f / (float)p->frames, (float*)nullptr, D, part);
-    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)part, AG_FIN_BLOCKS, loss);
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)part, fin_blocks, loss);
     // grad = x D:  A(m = t, k = f) = x[t * ld + f] (k unit stride), B(k = f, n = j) = D[f * ld + j]
     AgGemm g{};
     g.A = x; g.B = D; g.C = grad; g.M = p->frames; g.N = p->ld; g.K = p->ld; g.Ma = p->frames; g.Na = p->ld; g.Ka = p->ld;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profiles on the GPU box (one gpurun call): rocprofv3 kernel stats of the bench commands, the two
 # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs as MI355X_MICROARCH.md prescribes), step profiles.
-# Usage: bash tools/collect_profiles.sh r02   (writes gpurun_out/<tag>_*; copy what you want judged into profiles/)
+# Usage: bash tools/collect_profiles.sh r03   (writes gpurun_out/<tag>_*; copy what you want judged into profiles/)
 set -o pipefail
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -31,5 +31,12 @@ run rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --
 python tools/pmc_kernel.py $O/pmcv > $O/${TAG}_pmc_valu_mfma_64_clips.txt 2>&1
 python tools/step_profile.py > $O/${TAG}_step_profile_single_iteration.txt 2>&1
 python tools/step_profile.py 4 16 4 64 > $O/${TAG}_step_profile_64_clips.txt 2>&1
-rm -rf $O/p1 $O/p64 $O/pm1_* $O/pm64_* $O/pmcv
+# audio extension (not reference parity): kernel stats of its STFT / Gram / iteration kernels
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/pa -- python tools/audio_profile.py > $O/${TAG}_audio_profile.log 2>&1
+cp $O/pa/*/*kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats_audio_extension.csv
+# N > 1 rehearsals on this one GPU (gloo, every rank on cuda:0): data parallel and the tiled long clip
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+run python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --backend gloo --share-device --steps 40 --warmup 4 > $O/${TAG}_rehearsal_dp2_gloo_share_device.json 2> /dev/null
+run python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --backend gloo --share-device --tile-bars --steps 10 --warmup 2 > $O/${TAG}_rehearsal_tile2_gloo_share_device.json 2> /dev/null
+rm -rf $O/p1 $O/p64 $O/pm1_* $O/pm64_* $O/pmcv $O/pa
 ls -la $O | grep ${TAG}_ | head -30
