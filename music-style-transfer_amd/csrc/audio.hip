@@ -261,11 +261,16 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
     const int total = ld * ld;
     const int e = blockIdx.x * 256 + threadIdx.x;           // one element per lane: ceil(ld^2 / 256) workgroups
     if (e < total) {
+        // lane (i, j) with i >= j reads the stored (lower) element — consecutive lanes, consecutive addresses — and writes both
+        // (i, j) and its mirror (j, i); lanes above the diagonal only clear the pads they own.  (Letting every lane read "its"
+        // element made half the lanes walk a column of every slab.)
         const int i = e / ld, j = e - i * ld;
-        float gv = 0.f, dv = 0.f;
-        if (i < nb && j < nb) {
-            const int a = i >= j ? i : j, c = i >= j ? j : i;      // the stored (lower) element
-            const MST_GLOBAL_AS float* src = (const MST_GLOBAL_AS float*)slabs + ((int64_t)a * ld + c);
+        if (i >= nb || j >= nb) {
+            if (G) G[e] = 0.f;
+            if (D) D[e] = 0.f;
+        } else if (i >= j) {
+            const MST_GLOBAL_AS float* src = (const MST_GLOBAL_AS float*)slabs + e;
+            float gv = 0.f, dv = 0.f;
             int s = 0;
             for (; s + 8 <= splits; s += 8) {              // eight slab loads in flight, added in split order
                 float v[8];
@@ -276,10 +281,11 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restr
             }
             for (; s < splits; ++s) gv += src[(int64_t)s * slab_stride];
             gv *= inv_t;
-            if (gs) { const float df = gv - gs[e]; dv = cd * df; sq = df * df; }
+            if (gs) { const float df = gv - gs[e]; dv = cd * df; sq = i == j ? df * df : 2.f * df * df; }     // G_style is symmetric
+            const int et = j * ld + i;
+            if (G) { G[e] = gv; G[et] = gv; }
+            if (D) { D[e] = dv; D[et] = dv; }
         }
-        if (G) G[e] = gv;
-        if (D) D[e] = dv;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);

@@ -6,7 +6,7 @@ set -o pipefail
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-ONE="bench.py --steps 200 --warmup 20 --no-cpu-baseline --batched-clips 0 --surface-steps 0"
+ONE="bench.py --steps 200 --warmup 20 --no-cpu-baseline --batched-clips 0 --surface-steps 0 --audio-steps 0"
 B64="bench.py --clips-per-gpu 64 --steps 640 --warmup 64 --no-cpu-baseline"
 run() { echo "== $*" >&2; timeout -k 10 400 "$@"; echo "rc=$?" >&2; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python $ONE > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_p1.err
@@ -17,10 +17,10 @@ run rocprofv3 --kernel-trace --stats --output-format csv -d $O/p64 -- python $B6
 cp $O/p64/*/*kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats_64_clips.csv
 python tools/pass_timeline.py $O/p64 > $O/${TAG}_pass_timeline_64_clips.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  run rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pm1_$c -- python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-graph --no-roofline --batched-clips 0 --surface-steps 0 > /dev/null 2> $O/${TAG}_pm1_$c.err
+  run rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pm1_$c -- python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-graph --no-roofline --batched-clips 0 --surface-steps 0 --audio-steps 0 > /dev/null 2> $O/${TAG}_pm1_$c.err
   run rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pm64_$c -- python bench.py --clips-per-gpu 64 --steps 128 --warmup 64 --no-cpu-baseline --no-roofline > /dev/null 2> $O/${TAG}_pm64_$c.err
 done
-python tools/pmc_traffic.py $O/pm1_FETCH_SIZE $O/pm1_WRITE_SIZE $O/${TAG}_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-graph --no-roofline --batched-clips 0 --surface-steps 0 (two separate passes)" 1
+python tools/pmc_traffic.py $O/pm1_FETCH_SIZE $O/pm1_WRITE_SIZE $O/${TAG}_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-graph --no-roofline --batched-clips 0 --surface-steps 0 --audio-steps 0 (two separate passes)" 1
 python tools/pmc_traffic.py $O/pm64_FETCH_SIZE $O/pm64_WRITE_SIZE $O/${TAG}_pmc_hbm_traffic_64_clips.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --clips-per-gpu 64 --steps 128 --warmup 64 --no-cpu-baseline --no-roofline (two separate passes; per_iteration = per clip-iteration)" 64
 # bench lines kept beside the profiles: the default line, 32 / 64 clips per launch, the tiled long clip, VALU : MFMA per GEMM launch
 run python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
