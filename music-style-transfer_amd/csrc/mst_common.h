@@ -206,6 +206,7 @@ struct NotesDesc {
     // [SP_GRAD] (nblk, C, 240) and (nblk, C, 210); the loss tail's saved Jacobian and upstream loss gradients [SP_WS]
     int64_t itp_oct_off, itp_deg_off, loss_saved_off, loss_gl_off;
     // ME only: the channel combine (style/model.py:296,796-815) is fused in.  nwc waves per channel leave partial sums:
+    int32_t fhn;                 // me_notes_fwd: waves per q, each taking NF / fhn fractions (a divisor of NF)
     int32_t nwc;                 // <= 64
     int64_t part_off;            // [SP_TMP] forward: C*nwc partial sums of squares; backward: C*nwc partial a_c, then nwc partial b
     int64_t stats_off;           // [SP_TMP] n_c (C floats), S

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256, ME_FWD_MINW) void me_notes_fwd_kernel(const No
     __shared__ float nc_s[4][COMBINE_MAXC + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, gw = blockIdx.x * 4 + wv;
-    const int q = gw / ME_FH, fh = gw - q * ME_FH;
+    const int fhn = d.fhn;                                 // waves per q: 2 in batched plans, 10 (one fraction each) for one clip
+    const int q = gw / fhn, fh = gw - q * fhn;
     if (q >= d.Q) return;                                   // wave-uniform
     float* tmp = b.p[SP_TMP];
     float S = 0.f;
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(256, ME_FWD_MINW) void me_notes_fwd_kernel(const No
     const int n = valid ? lane : NPN - 1, o = n / NDEG, dg = n - o * NDEG;
     const float* x = b.p[d.x_space] + d.x_off;
     float* ws = b.p[SP_WS];
-    constexpr int F0 = NF / ME_FH;
-    const int f_begin = fh * F0, f_end = fh == ME_FH - 1 ? NF : f_begin + F0;
+    const int F0 = NF / fhn;
+    const int f_begin = fh * F0, f_end = fh == fhn - 1 ? NF : f_begin + F0;
     // fractions outside, channels inside (one accumulator row live): the octave / degree half is recomputed per (fraction, channel)
     // here — keeping it across the half's five fractions needs five accumulator rows and costs two of the four waves per SIMD
     for (int f = f_begin; f < f_end; ++f) {
@@ -870,7 +871,7 @@ int launch_me_bwd_reduce(const NotesDesc* dev, const NotesDesc& h, int count, Ba
     return (int)hipGetLastError();
 }
 int launch_me_notes_fwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {
-    ME_DISPATCH(me_notes_fwd_kernel, dim3((h.Q * ME_FH + 3) / 4, count), dim3(256));
+    ME_DISPATCH(me_notes_fwd_kernel, dim3((h.Q * h.fhn + 3) / 4, count), dim3(256));
     return (int)hipGetLastError();
 }
 int launch_me_notes_bwd(const NotesDesc* dev, const NotesDesc& h, int count, Bases b, hipStream_t s) {

@@ -957,6 +957,9 @@ void mst_plan::build() {
         // (the same count for every clip count: the grouping of the partial sums decides the last bits of n_c, and a clip's
         // activations are bit-identical in one-clip and batched plans)
         n.nwc = Q_ < 64 ? Q_ : 64;
+        // forward: a wave per (q, group of fractions).  One clip per launch is latency-bound and wants every wave it can get
+        // (a wave per fraction: 10 x Q waves); batched plans have the clips for that and keep two waves per q
+        n.fhn = K() == 1 ? NF : 2;
         n.part_off = tmp((int64_t)(C + 1) * n.nwc); n.stats_off = tmp(C + 1);
         // backward: two waves per position (one per half of the fractions), two positions per workgroup up to the cap; every
         // wave leaves one slab row for the deferred reduction
