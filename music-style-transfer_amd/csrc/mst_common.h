@@ -212,6 +212,19 @@ struct NotesDesc {
     int64_t stats_off;           // [SP_TMP] n_c (C floats), S
 };
 
+// ---- the note-axis convolution of batched plans on its own kernels (conv.hip): ONE descriptor for all clips
+struct ConvDesc {
+    int32_t P, clips, OC, splits;        // positions per clip, clips, out channels (57), k-splits of the weight gradient
+    int64_t rows_per_split;              // rows (position, octave) per split: a multiple of 32
+    int64_t x1_off, clip_stride;         // conv output (P, OC * 8) [SP_WS / SP_GRAD], floats between two clips' arenas
+    int64_t wp_off;                      // [SP_TMP, clip 0] permuted, zero-padded weights W' (720 x 64)
+    int64_t w_off, b_off;                // [SP_PAR] Conv1d weight (OC, 50, 14), bias
+    int64_t slab_off, slab_stride;       // [SP_TMP, clip 0] one slab of OC * 700 + OC per split, parameter layout
+};
+int launch_conv_prep(const ConvDesc& d, Bases b, hipStream_t s);
+int launch_conv_fwd(const ConvDesc& d, Bases b, hipStream_t s);
+int launch_conv_dw(const ConvDesc& d, Bases b, hipStream_t s);
+
 // ---- row-wise tiny Linear: y[r, :] = act(W x[r, :] + b) with K_in <= 8 and N_out <= 20 over very many rows
 // (PitchedStyleApplier.melody_linear 8->20 over positions x 56 notes, UnpitchedStyleApplier.linear 8->2 over
 // positions x 47 notes; style/model.py:606-610,660-662,694-701,722-723).  As GEMMs these are all tile padding.

@@ -199,7 +199,8 @@ enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_
        K_ME_SQ, K_ME_RED,
        // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
        K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG,
-       K_GEMM_FOLD };      // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
+       K_GEMM_FOLD,        // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
+       K_CONV_P, K_CONV_F, K_CONV_W };      // batched plans on the 64x64 tiling: the note-axis convolution on its own kernels (conv.hip), one descriptor for all clips
 struct Step { int kind, first, count, a, b, stage; int c = 0; int lvl = 0; };      // c: GEMM steps — offset of the step's block -> member table; lvl: dependency level in its scheduled pass
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
@@ -210,6 +211,7 @@ struct mst_plan {
     mst_dims d; Sizes z; ParamTable pt;
     std::vector<GemmDesc> gemms; std::vector<GatherDesc> gathers; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
     std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<RowLinDesc> rowlins; std::vector<SlabEntry> slabs[3];
+    std::vector<ConvDesc> convs;
     std::vector<Op> ops;
     // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
     std::vector<Step> sched[2];        // per-stage merging (stages may run separately)
@@ -489,6 +491,30 @@ struct mst_plan {
         const int64_t boff = pt.off("pitched_channels_encoder.beats_conv.module.bias");
         const int K = NF * NPF * CONV_K;
         Op op; op.stage = stage;
+        // batched plans on the 64x64 tiling: forward and weight gradient on conv.hip's kernels (window loads instead of per-element
+        // im2col index math, 256 x 64 / 64 x 256 tiles); all clips are rows of ONE launch
+        if (folds_clips() && z.OC <= 64 && P_ >= 8 && (int64_t)this->K() * P_ * NF * NPN * NPF < ((int64_t)1 << 32)) {
+            ConvDesc c{}; c.P = P_; c.clips = this->K(); c.OC = z.OC; c.x1_off = x1.off; c.w_off = woff; c.b_off = boff;
+            c.wp_off = tmp((int64_t)NF * 72 * 64);
+            const int64_t rows = (int64_t)this->K() * P_ * NOCT;
+            int64_t sp = 170;                                 // 3 column tiles x 170 splits = 510 workgroups: two rounds of the chip
+            int64_t per = ((rows + sp - 1) / sp + 31) / 32 * 32;
+            if (per < 256) per = 256;
+            c.rows_per_split = per; c.splits = (int)((rows + per - 1) / per);
+            c.slab_stride = (int64_t)z.OC * K + z.OC;
+            c.slab_off = tmp(c.slab_stride * c.splits);
+            const int ci = (int)convs.size();
+            convs.push_back(c);
+            op.fwd.push_back(Step{K_CONV_P, ci, 1, 0, 0});
+            op.fwd.push_back(Step{K_CONV_F, ci, 1, 0, 0});
+            op.bwd.push_back(Step{K_CONV_W, ci, 1, 0, 0});
+            SlabEntry e1{woff, c.slab_off, c.slab_stride, z.OC * K, c.splits}, e2{boff, c.slab_off + (int64_t)z.OC * K, c.slab_stride, z.OC, c.splits};
+            e1.single = e2.single = 1;
+            slabs[stage_idx(stage)].push_back(e1);
+            slabs[stage_idx(stage)].push_back(e2);
+            ops.push_back(op);
+            return x1;
+        }
         GemmDesc g{}; g.M = P_ * NOCT; g.N = z.OC; g.K = K; g.ksplit = 1;
         g.A.kind = OPK_IM2COL; g.A.space = SP_EXT0; g.A.off = 0; g.A.ones_at = -1; g.A.kfast = 1;
         g.B.kind = OPK_PERMW; g.B.space = SP_PAR; g.B.off = woff; g.B.ld = K; g.B.pb = CONV_K; g.B.pc = NPF; g.B.kfast = 1;
@@ -1147,6 +1173,15 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             else acc_add(v, o.space, o.off, o.slab_stride * g.ksplit, true);
             break;
         }
+        case K_CONV_P: case K_CONV_F: case K_CONV_W: {
+            if (i > 0) break;
+            const ConvDesc& c = convs[s.first];
+            const int64_t n = (int64_t)c.P * c.OC * NOCT;
+            if (s.kind == K_CONV_P) acc_add(v, SP_TMP, c.wp_off, (int64_t)NF * 72 * 64, true);
+            else if (s.kind == K_CONV_F) { acc_add(v, SP_TMP, c.wp_off, (int64_t)NF * 72 * 64, false); acc_add(v, SP_WS, c.x1_off, n, true); }
+            else { acc_add(v, SP_WS, c.x1_off, n, false); acc_add(v, SP_GRAD, c.x1_off, n, false); acc_add(v, SP_TMP, c.slab_off, c.slab_stride * c.splits, true); }
+            break;
+        }
         case K_GATHER: {
             const GatherDesc& g = gathers[s.first + i];
             for (int q = 0; q < g.nseg; ++q) {
@@ -1378,7 +1413,7 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
             // The W_hh transpose reads parameters only, so it runs once for all clips.
             // (the multi-workgroup flavour's K_LSTM_T step clears per-clip exchange tags instead: one copy per clip)
             const bool shared_T = s0.kind == K_LSTM_T && !lstms[s0.first].multi;
-            const int copies = (shared_T || s0.kind == K_GEMM_FOLD) ? 1 : K();
+            const int copies = (shared_T || s0.kind == K_GEMM_FOLD || s0.kind >= K_CONV_P) ? 1 : K();
             for (int k = 0; k < copies; ++k) {
                 for (int idx : members) {
                     if (s0.kind == K_GEMM || s0.kind == K_GEMM_FOLD) {
@@ -1755,6 +1790,9 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_FOLD: return launch_fold(p->d_folds + s.first, 0, b, st);
     case K_SPREAD: return launch_fold(p->d_folds + s.first, 1, b, st);
     case K_XCHG: return MST_ERR_UNSUPPORTED;        // a tiled plan runs through mst_tiled_phase, which stops at exchanges
+    case K_CONV_P: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_prep(c, b, st); }
+    case K_CONV_F: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_fwd(c, b, st); }
+    case K_CONV_W: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_dw(c, b, st); }
     case K_ROW_F: return launch_rowlin_fwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ROW_B: return launch_rowlin_bwd(p->d_rowlins + s.first, p->s_rowlins[s.first], s.count, b, st);
     case K_ME_SQ: return launch_me_sumsq(p->d_notes + s.first, p->s_notes[s.first], s.count, b, st);
@@ -1954,6 +1992,13 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
     case K_GATHER:
         for (int i = 0; i < s.count; ++i) { const GatherDesc& g = p->s_gathers[s.first + i]; b += 8.0 * g.rows * g.K; }
         break;
+    case K_CONV_F: case K_CONV_W: {
+        const ConvDesc& c = p->convs[s.first];
+        const double rows = (double)c.clips * c.P * NOCT, kk = NF * NPF * CONV_K;
+        f = 2.0 * rows * c.OC * kk;
+        b = 4.0 * (rows / NOCT * NF * NPN * NPF + rows * c.OC * (s.kind == K_CONV_F ? 1.0 : 2.0) + c.OC * kk);
+        break;
+    }
     case K_SEGRED:
         for (int i = 0; i < s.count; ++i) {
             const SegRedDesc& r = p->s_segreds[s.first + i];
