@@ -82,14 +82,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
         const int f = kt >> 1, h = kt & 1;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
+            // Branch-free: ONE 16-byte load per group whatever its position.  The window offsets are 35 oct - 20 + 4 n, so a group
+            // is wholly in front of the row (octave 0: conv padding), wholly inside, wholly behind it, or — octave 7 only — starts
+            // at element 277 and has exactly its last element outside: that one is loaded one element early and shifted.
             const int e = e0[q] + CV_KT * h;                           // first element of the group inside the row
-            const unsigned o = xoff[q] + (unsigned)(f * CV_ROW) + (unsigned)e;
-            cv_f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e >= 0 && e + 3 < CV_ROW) v = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + o);
-            else if (e + 3 >= 0 && e < CV_ROW) {                       // a group on the row's edge: element by element
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (e + j >= 0 && e + j < CV_ROW) ? x[o + j] : 0.f;
-            }
+            const bool part = e == CV_ROW - 3, ok = e >= 0 && e <= CV_ROW - 3;
+            const int es = ok ? (part ? e - 1 : e) : 0;
+            const cv_f4 t = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (xoff[q] + (unsigned)(f * CV_ROW) + (unsigned)es));
+            cv_f4 v;
+            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
+            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
             ra[q] = v;
         }
 #pragma unroll
@@ -186,43 +188,52 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(const ConvDesc d, Bases
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     cv_f4 rg[2], ry[2], rb[8];
     const int na = 4 * d.OC * 2;                                       // A items per k-tile
+    // the lane's two A items (position slot, out channel, octave half) never change
+    int a_p4[2], a_col[2], a_lds[2];
+    bool a_on[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int item = tid + 256 * q;
+        a_on[q] = item < na;
+        const int it = a_on[q] ? item : 0;
+        const int p4 = it / (2 * d.OC), rem = it - p4 * (2 * d.OC), oc = rem >> 1, half = rem & 1;
+        a_p4[q] = p4; a_col[q] = oc * NOCT + 4 * half; a_lds[q] = (p4 * 8 + 4 * half) * PA + oc;
+    }
+    // (clip, position inside the clip) of the k-tile's first position, advanced by four positions per k-tile: no division in the loop
+    unsigned t_clip = (unsigned)((k0 >> 3) / d.P), t_pl = (unsigned)((k0 >> 3) - (int64_t)t_clip * d.P);
     auto issue = [&](const int64_t kt) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int item = tid + 256 * q;
             cv_f4 g4 = {0.f, 0.f, 0.f, 0.f}, y4 = {1.f, 1.f, 1.f, 1.f};
-            if (item < na) {
-                const int p4 = item / (2 * d.OC), rem = item - p4 * (2 * d.OC), oc = rem >> 1, half = rem & 1;
-                const int64_t pg = (kt >> 3) + p4;
-                if (pg * NOCT < k1) {                                   // (k0 and k1 are multiples of 8 except the very end: whole positions)
-                    const int64_t clip = pg / d.P, pl = pg - clip * d.P;
-                    const int64_t o = clip * d.clip_stride + d.x1_off + pl * (int64_t)(d.OC * NOCT) + oc * NOCT + 4 * half;
-                    g4 = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(gr + o);
-                    y4 = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(ws + o);
-                }
+            unsigned clip = t_clip, pl = t_pl + (unsigned)a_p4[q];
+            while (pl >= (unsigned)d.P) { pl -= (unsigned)d.P; ++clip; }
+            if (a_on[q] && ((kt >> 3) + a_p4[q]) * NOCT < k1) {          // (k0 and k1 are multiples of 8: whole positions)
+                const int64_t o = (int64_t)clip * d.clip_stride + d.x1_off + (int64_t)pl * (d.OC * NOCT) + a_col[q];
+                g4 = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(gr + o);
+                y4 = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(ws + o);
             }
             rg[q] = g4; ry[q] = y4;
         }
+        t_pl += 4;
+        while (t_pl >= (unsigned)d.P) { t_pl -= (unsigned)d.P; ++t_clip; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int row = (tid >> 6) + 4 * q;                         // row of the k-tile: position slot row >> 3, octave row & 7
             const int64_t m = kt + row;
-            cv_f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (bcol && m < k1) {
-                const int64_t pg = m >> 3;
-                const int oct = (int)(m & 7);
-                const int e = 35 * oct - 20 + br;
-                const unsigned o = (unsigned)(pg * (NF * CV_ROW)) + (unsigned)(bf * CV_ROW) + (unsigned)e;
-                if (br + 3 < CONV_K * NPF && e >= 0 && e + 3 < CV_ROW) v = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + o);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = br + j < CONV_K * NPF && e + j >= 0 && e + j < CV_ROW;
-                        v[j] = ok ? x[o + j] : 0.f;
-                    }
-                }
-                if (kp <= CONV_K * NPF && kp + 3 >= CONV_K * NPF) v[CONV_K * NPF - kp] = 1.f;      // k' = 70: the bias-gradient column
-            }
+            // branch-free like the forward's: one 16-byte load per group; the two pad columns of a fraction (r = 70, 71) may hold
+            // anything finite (their products are never stored) except k' = 70, the bias-gradient column, which is 1
+            const bool live = bcol && m < k1;
+            const int64_t mm = live ? m : k0;
+            const unsigned pg = (unsigned)(mm >> 3);
+            const int oct = (int)(mm & 7);
+            const int e = 35 * oct - 20 + br;
+            const bool part = e == CV_ROW - 3, ok = live && e >= 0 && e <= CV_ROW - 3;
+            const int es = ok ? (part ? e - 1 : e) : 0;
+            const cv_f4 t = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (pg * (unsigned)(NF * CV_ROW) + (unsigned)(bf * CV_ROW) + (unsigned)es));
+            cv_f4 v;
+            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
+            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
+            if (live && kp == CONV_K * NPF - 2) v[2] = 1.f;              // k' = 70 sits at element 2 of the group that starts at 68
             rb[q] = v;
         }
     };
@@ -231,11 +242,10 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(const ConvDesc d, Bases
     for (int64_t kt = k0; kt < k1; kt += KT) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int item = tid + 256 * q;
-            if (item < na) {
-                const int p4 = item / (2 * d.OC), rem = item - p4 * (2 * d.OC), oc = rem >> 1, half = rem & 1;
+            if (a_on[q]) {
+                float* af = &As[0][0] + a_lds[q];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) As[p4 * 8 + 4 * half + j][oc] = rg[q][j] * (ry[q][j] > 0.f ? 1.f : LEAKY);
+                for (int j = 0; j < 4; ++j) af[j * PA] = rg[q][j] * (ry[q][j] > 0.f ? 1.f : LEAKY);
             }
         }
 #pragma unroll
