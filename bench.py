@@ -36,7 +36,7 @@ KIND_NAMES = {0: 'gemm_kernel', 1: 'gather_kernel', 2: 'segred_kernel', 3: 'lstm
               5: 'combine_fwd', 6: 'combine_bwd', 7: 'me_notes_fwd_kernel', 8: 'me_notes_bwd_kernel',
               9: 'psa_notes_fwd_kernel', 10: 'psa_notes_bwd_kernel', 11: 'lstm_transpose_kernel', 12: 'rowlin_fwd_kernel',
               13: 'rowlin_bwd_kernel', 14: 'me_reduce_kernel(fwd)', 15: 'me_reduce_kernel(bwd)', 26: 'conv_prep_kernel',
-              27: 'conv_fwd_kernel', 28: 'conv_dw_kernel'}
+              27: 'conv_fwd_kernel', 28: 'conv_dw_kernel', 29: 'lin_fwd_kernel', 30: 'lin_dx_kernel', 31: 'lin_dw_kernel'}
 
 
 def algorithmic_flops_per_iter(C, R, T, U=1):

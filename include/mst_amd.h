@@ -87,7 +87,10 @@ typedef struct {
                                  * else one workgroup per sequence); 1 = always one workgroup per sequence (use it when other kernels are
                                  * meant to run beside a batched plan); 2 = the 12-workgroup kernels with an injected exchange fault
                                  * (tests of the mst_plan_status path only) */
-    int32_t reserved[2];        /* must be 0 */
+    int32_t dense_flavour;      /* large dense nn.Linear layers of plans on the 64x64 tiling (lin.hip: all clips as rows of one launch, 2 x 2-blocked
+                                 * MFMA tiles): 0 = choose (layers of >= 512 rows and >= 4 MFLOP per clip with more than 32 outputs), 1 = never, 2 = every eligible layer (parity tests
+                                 * at small sizes) */
+    int32_t reserved[1];        /* must be 0 */
 } mst_plan_options;
 mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
 mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);
@@ -197,9 +200,10 @@ int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_
 /* ---- instrumentation (bench.py only; synchronises on HIP events, never used for training):
  * average duration of every launch step of a pass, with its algorithmic FLOPs and bytes.
  * kind: 0 gemm, 1 gather, 2 segment-reduce, 3/4 lstm fwd/bwd, 5/6 combine fwd/bwd, 7/8 melody notes, 9/10 applier notes,
- * 11 lstm weight transpose, 12/13 row-wise tiny Linear fwd/bwd. */
+ * 11 lstm weight transpose, 12/13 row-wise tiny Linear fwd/bwd, ..., 26-28 conv.hip prep / forward / weight gradient,
+ * 29-31 lin.hip forward / input gradient / weight gradient. */
 int32_t mst_plan_step_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
-int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 5 ints per step */);
+int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 6 ints per step: 4 shape values, member count, kind */);
 /* (new) instrumentation: the members of GEMM launch step `step` of a pass, one clip's worth, 6 values each:
  * {M, N, K, k-splits, folded rows per clip (0 = not folded), workgroups}.  Returns the member count (<= cap). */
 int32_t mst_plan_step_gemms(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t step, int32_t* out, int32_t cap);

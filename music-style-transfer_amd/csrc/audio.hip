@@ -206,26 +206,8 @@ __global__ __launch_bounds__(256, 2) void ag_gemm_kernel(const AgGemm g) {
             }
             MST_LDS_BARRIER();                              // (a wave past this barrier has finished reading the other buffer)
             if (kt + AG_KT < k1) issue(kt + AG_KT);        // flies under this k-tile's MFMAs and across the next barrier
-            if constexpr (decltype(LM0)::value) {
-#pragma unroll
-                for (int s = 0; s < AG_KT / 2; ++s) {
-                    const int k = 2 * s + kh;
-                    const float a0 = As[buf][k][wm * 64 + l31], b0 = Bs[buf][k][wn * 64 + l31];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    if constexpr (decltype(LN1)::value) {
-                        const float b1 = Bs[buf][k][wn * 64 + 32 + l31];
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                        if constexpr (decltype(LM1)::value) {
-                            const float a1 = As[buf][k][wm * 64 + 32 + l31];
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                        }
-                    } else if constexpr (decltype(LM1)::value) {
-                        const float a1 = As[buf][k][wm * 64 + 32 + l31];
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    }
-                }
-            }
+            if constexpr (decltype(LM0)::value)
+                mst_mfma_ktile_2x2<AG_KT, decltype(LM1)::value, decltype(LN1)::value>(As[buf], Bs[buf], wm * 64, wn * 64, l31, kh, acc);
             buf ^= 1;
         }
     };

@@ -24,7 +24,7 @@
 #define CV_KT 36                 // k-tile
 #define CV_K (NF * CV_KP)        // 720
 #define CV_ROW (NPN * NPF)       // 280 floats of one (position, fraction)
-typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
+typedef mst_f32x16 cv_f32x16;
 typedef float cv_f4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef const MST_GLOBAL_AS float* cv_gp;
 
@@ -85,14 +85,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
             // Branch-free: ONE 16-byte load per group whatever its position.  The window offsets are 35 oct - 20 + 4 n, so a group
             // is wholly in front of the row (octave 0: conv padding), wholly inside, wholly behind it, or — octave 7 only — starts
             // at element 277 and has exactly its last element outside: that one is loaded one element early and shifted.
+            // (the shift / zeroing is applied when the k-tile is committed to LDS, so the load stays in flight under the MFMAs)
             const int e = e0[q] + CV_KT * h;                           // first element of the group inside the row
             const bool part = e == CV_ROW - 3, ok = e >= 0 && e <= CV_ROW - 3;
             const int es = ok ? (part ? e - 1 : e) : 0;
-            const cv_f4 t = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (xoff[q] + (unsigned)(f * CV_ROW) + (unsigned)es));
-            cv_f4 v;
-            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
-            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
-            ra[q] = v;
+            ra[q] = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (xoff[q] + (unsigned)(f * CV_ROW) + (unsigned)es));
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -106,9 +103,16 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
     for (int kt = 0; kt < CV_K / CV_KT; ++kt) {
         float* af = &As[0][0];
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
+        for (int q = 0; q < 9; ++q) {
+            const int e = e0[q] + CV_KT * (kt & 1);
+            const bool part = e == CV_ROW - 3, ok = e >= 0 && e <= CV_ROW - 3;
+            const cv_f4 t = ra[q];
+            cv_f4 v;
+            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
+            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[lds_a[q] + j * PA] = ra[q][j];
+            for (int j = 0; j < 4; ++j) af[lds_a[q] + j * PA] = v[j];
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int item = tid + 256 * q;
@@ -119,16 +123,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
         }
         MST_LDS_BARRIER();
         if (kt + 1 < CV_K / CV_KT) issue(kt + 1);                      // flies under this k-tile's 72 MFMAs per wave
-#pragma unroll
-        for (int s = 0; s < CV_KT / 2; ++s) {
-            const int k = 2 * s + kh;
-            const float a0 = As[k][wv * 64 + l31], a1 = As[k][wv * 64 + 32 + l31];
-            const float b0 = Bs[k][l31], b1 = Bs[k][32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        mst_mfma_ktile_2x2<CV_KT>(As, Bs, wv * 64, 0, l31, kh, acc);
         MST_LDS_BARRIER();                                              // single LDS buffer: everyone is done reading before the next stores
     }
     // epilogue: x1[clip][p][oc * 8 + oct] = leaky(acc + bias[oc]).  A lane's 32 rows are 8 positions x 4 octaves: one division
@@ -229,12 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(const ConvDesc d, Bases
             const int e = 35 * oct - 20 + br;
             const bool part = e == CV_ROW - 3, ok = live && e >= 0 && e <= CV_ROW - 3;
             const int es = ok ? (part ? e - 1 : e) : 0;
-            const cv_f4 t = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (pg * (unsigned)(NF * CV_ROW) + (unsigned)(bf * CV_ROW) + (unsigned)es));
-            cv_f4 v;
-            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
-            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
-            if (live && kp == CONV_K * NPF - 2) v[2] = 1.f;              // k' = 70 sits at element 2 of the group that starts at 68
-            rb[q] = v;
+            rb[q] = *reinterpret_cast<const MST_GLOBAL_AS cv_f4*>(x + (pg * (unsigned)(NF * CV_ROW) + (unsigned)(bf * CV_ROW) + (unsigned)es));
         }
     };
     for (int e = tid; e < KT * (64 - d.OC); e += 256) As[e / (64 - d.OC)][d.OC + e % (64 - d.OC)] = 0.f;      // unused out-channel columns: zero, once
@@ -250,21 +240,22 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(const ConvDesc d, Bases
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            // the shift / zeroing of the group loaded by issue(kt), applied here so that the load flew under the previous MFMAs
+            const int64_t m = kt + (tid >> 6) + 4 * q;
+            const bool live = bcol && m < k1;
+            const int e = 35 * (int)(m & 7) - 20 + br;
+            const bool part = e == CV_ROW - 3, ok = live && e >= 0 && e <= CV_ROW - 3;
+            const cv_f4 t = rb[q];
+            cv_f4 v;
+            v[0] = ok ? (part ? t[1] : t[0]) : 0.f; v[1] = ok ? (part ? t[2] : t[1]) : 0.f;
+            v[2] = ok ? (part ? t[3] : t[2]) : 0.f; v[3] = (ok && !part) ? t[3] : 0.f;
+            if (live && kp == CONV_K * NPF - 2) v[2] = 1.f;              // k' = 70 sits at element 2 of the group that starts at 68
             float* dst = &Bs[(tid >> 6) + 4 * q][4 * (tid & 63)];
-            dst[0] = rb[q][0]; dst[1] = rb[q][1]; dst[2] = rb[q][2]; dst[3] = rb[q][3];
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
         }
         MST_LDS_BARRIER();
         if (kt + KT < k1) issue(kt + KT);
-#pragma unroll
-        for (int s = 0; s < KT / 2; ++s) {
-            const int k = 2 * s + kh;
-            const float a0 = As[k][l31], a1 = As[k][32 + l31];
-            const float b0 = Bs[k][wv * 64 + l31], b1 = Bs[k][wv * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        mst_mfma_ktile_2x2<KT>(As, Bs, 0, wv * 64, l31, kh, acc);
         MST_LDS_BARRIER();
     }
     // epilogue: this split's slab, in PARAMETER layout: weight (OC x 50 x 14) then bias (OC)

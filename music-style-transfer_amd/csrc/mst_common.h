@@ -71,7 +71,8 @@
 enum { SP_WS = 0, SP_PAR = 1, SP_GPAR = 2, SP_EXT0 = 3, SP_EXT1 = 4, SP_GRAD = 5, SP_TMP = 6, SP_COUNT = 7 };
 // flags: MST_BF_LOSS_FUSED — this backward pass belongs to mst_train_iteration: the gradient of the pitched prediction is not in
 // its gradient slot; the applier's backward kernel derives it from (prediction, target, the loss tail's saved Jacobian) itself
-enum { MST_BF_LOSS_FUSED = 1 };
+enum { MST_BF_LOSS_FUSED = 1,
+       MST_BF_ALL_STAGES = 2 };    // the pass walks the whole-model launch list (selects LinDesc.first[1])
 struct Bases { float* p[SP_COUNT]; int32_t flags; };
 
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SIGOUT = 2, ACT_BPM = 3 };
@@ -224,6 +225,53 @@ struct ConvDesc {
 int launch_conv_prep(const ConvDesc& d, Bases b, hipStream_t s);
 int launch_conv_fwd(const ConvDesc& d, Bases b, hipStream_t s);
 int launch_conv_dw(const ConvDesc& d, Bases b, hipStream_t s);
+
+// The 2 x 2-blocked MFMA body shared by conv.hip / lin.hip: a wave's 64 x 64 outputs (four f32 32x32x2 accumulators) over one
+// staged k-tile of KT rows, As[k][PA] / Bs[k][PB] k-major in LDS.  The operands of k-step s + 1 are read from LDS BEFORE the four
+// MFMAs of step s are issued (two register sets): written the plain way (read, then use) the compiler waits lgkmcnt(0) in front of
+// every group of four MFMAs and the LDS latency is exposed 16 times per k-tile (PMC: 60 % MFMA-busy at two waves per SIMD).
+typedef float mst_f32x16 __attribute__((ext_vector_type(16)));
+template <int KT, bool M1 = true, bool N1 = true, int PA = 0, int PB = 0>
+__device__ __forceinline__ void mst_mfma_ktile_2x2(const float (*As)[PA], const float (*Bs)[PB], int arow, int bcol, int l31, int kh,
+                                                   mst_f32x16 (&acc)[2][2]) {
+    // M1 / N1: the wave's second 32-row / 32-column block is live (ragged tiles skip the dead blocks' MFMAs and reads)
+    float a0[2], a1[2], b0[2], b1[2];
+    a0[0] = As[kh][arow + l31]; b0[0] = Bs[kh][bcol + l31];
+    if (M1) a1[0] = As[kh][arow + 32 + l31];
+    if (N1) b1[0] = Bs[kh][bcol + 32 + l31];
+#pragma unroll
+    for (int s = 0; s < KT / 2; ++s) {
+        const int c = s & 1, n = c ^ 1;
+        if (s + 1 < KT / 2) {
+            const int k = 2 * (s + 1) + kh;
+            a0[n] = As[k][arow + l31]; b0[n] = Bs[k][bcol + l31];
+            if (M1) a1[n] = As[k][arow + 32 + l31];
+            if (N1) b1[n] = Bs[k][bcol + 32 + l31];
+        }
+        __builtin_amdgcn_sched_barrier(0);           // (the scheduler otherwise sinks the reads back behind the MFMAs to save four registers)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
+        if (N1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
+        if (M1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
+        if (M1 && N1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+// ---- dense nn.Linear of batched plans on its own kernels (lin.hip): ONE descriptor for all clips
+struct LinDesc {
+    int32_t rows, K, N, act, xgrad, clips;       // rows per clip; Linear K -> N
+    int32_t x_space, x_ld; int64_t x_off, x_cs;  // input rows at base[x_space] + x_off + clip * x_cs + r * x_ld
+    int32_t y_ld; int64_t y_off, y_cs;           // output rows [SP_WS] and their gradient [SP_GRAD]
+    int64_t gx_cs;                               // clip stride of the input's gradient [SP_GRAD, at x_off / x_ld]
+    int64_t w_off, b_off;                        // [SP_PAR] weight (N x K), bias (N)
+    int64_t slab_off, slab_stride, rows_per_split; int32_t splits;   // dW | db slabs [SP_TMP, clip 0], parameter layout
+    int32_t first[2];                            // dX stores instead of accumulating: in the per-stage / the whole-model backward list
+};
+int launch_lin_fwd(const LinDesc& d, Bases b, hipStream_t s);
+int launch_lin_dx(const LinDesc& d, Bases b, int first, hipStream_t s);
+int launch_lin_dw(const LinDesc& d, Bases b, hipStream_t s);
+int lin_dw_tiles(const LinDesc& d);
 
 // ---- row-wise tiny Linear: y[r, :] = act(W x[r, :] + b) with K_in <= 8 and N_out <= 20 over very many rows
 // (PitchedStyleApplier.melody_linear 8->20 over positions x 56 notes, UnpitchedStyleApplier.linear 8->2 over

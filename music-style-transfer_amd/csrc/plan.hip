@@ -200,7 +200,8 @@ enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_
        // tiled plans only (never merged): halves of a combine, strided copies, fold / spread around an exchange, the exchange
        K_COMB_F1, K_COMB_F2, K_COMB_B1, K_COMB_B2, K_COPY_F, K_COPY_B, K_FOLD, K_SPREAD, K_XCHG,
        K_GEMM_FOLD,        // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
-       K_CONV_P, K_CONV_F, K_CONV_W };      // batched plans on the 64x64 tiling: the note-axis convolution on its own kernels (conv.hip), one descriptor for all clips
+       K_CONV_P, K_CONV_F, K_CONV_W,
+       K_LIN_F, K_LIN_A, K_LIN_W };     // ... and its large dense nn.Linear layers (lin.hip): forward, input gradient, weight gradient      // batched plans on the 64x64 tiling: the note-axis convolution on its own kernels (conv.hip), one descriptor for all clips
 struct Step { int kind, first, count, a, b, stage; int c = 0; int lvl = 0; };      // c: GEMM steps — offset of the step's block -> member table; lvl: dependency level in its scheduled pass
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
@@ -211,7 +212,7 @@ struct mst_plan {
     mst_dims d; Sizes z; ParamTable pt;
     std::vector<GemmDesc> gemms; std::vector<GatherDesc> gathers; std::vector<SegRedDesc> segreds; std::vector<LstmDesc> lstms;
     std::vector<CombineDesc> combines; std::vector<NotesDesc> notes; std::vector<RowLinDesc> rowlins; std::vector<SlabEntry> slabs[3];
-    std::vector<ConvDesc> convs;
+    std::vector<ConvDesc> convs; std::vector<LinDesc> lins;
     std::vector<Op> ops;
     // scheduled launch lists (dependency-levelled, same-level steps merged) and their descriptor arrays
     std::vector<Step> sched[2];        // per-stage merging (stages may run separately)
@@ -343,7 +344,8 @@ struct mst_plan {
     // capped at 64 slabs, for workgroup count.  Batched plans get their parallelism from the clips, so a split covers
     // up to 2048 rows (64 MFMA k-tiles, at 64 clips) and the slab traffic of the deferred reduction shrinks accordingly.
     // batched plans on the 64x64 tiling fold the clips into the reduction of their weight-gradient GEMMs (GemmDesc.fold_rows)
-    bool folds_clips() const { return K() > 1 && (opt.gemm_tile == 64 || (opt.gemm_tile == 0 && K() >= 6)); }
+    bool mfma_plan() const { return opt.gemm_tile == 64 || (opt.gemm_tile == 0 && K() >= 6); }      // the throughput GEMM tiling
+    bool folds_clips() const { return K() > 1 && mfma_plan(); }
     // k-splits of a folded reduction: enough (tile, split) workgroups to fill every workgroup slot of the chip once (256 CUs x 4), at least
     // 128 reduction rows per split; the slab a split writes is one weight gradient, so many splits of a small weight are cheap
     int fold_splits(int rows, int M, int N, int members) const {
@@ -438,6 +440,35 @@ struct mst_plan {
         T out = out_opt ? *out_opt : newT(rows, N, name);
         const int64_t woff = pt.off(wname), boff = pt.off(bname);
         Op op; op.stage = stage;
+        // Plans on the throughput tiling run their large dense Linears on lin.hip's kernels (2 x 2-blocked MFMA tiles, all clips
+        // as rows of one launch): row-major input in the workspace or a borrowed note tensor, >= 512 rows and >= 4 MFLOP per clip
+        // and more than one 32-column MFMA block of outputs.  The rule does not look at the clip count: a one-clip plan forced
+        // onto this tiling takes the same kernels, so "batched == one clip at a time, bit for bit" holds by construction.
+        if (mfma_plan() && opt.dense_flavour != 1 && !pb && rows >= 32 && K >= 4 && N >= 4 && (space == SP_WS || ((space == SP_EXT0 || space == SP_EXT1) && !xgrad)) &&
+            boff == woff + (int64_t)N * K && (int64_t)this->K() * rows < ((int64_t)1 << 30) &&
+            (opt.dense_flavour == 2 || (rows >= 512 && N > 32 && 2.0 * rows * N * K >= 4e6))) {
+            LinDesc l{}; l.rows = rows; l.K = K; l.N = N; l.act = act; l.xgrad = xgrad ? 1 : 0; l.clips = this->K();
+            l.x_space = space; l.x_ld = xld; l.x_off = xoff; l.y_ld = out.ld; l.y_off = out.off; l.w_off = woff; l.b_off = boff;
+            const int64_t mtot = (int64_t)this->K() * rows;
+            const int tl = lin_dw_tiles(l);
+            int64_t sp = std::max<int64_t>(1, 512 / tl);
+            int64_t per = ((mtot + sp - 1) / sp + 31) / 32 * 32;
+            if (per < 128) per = 128;
+            l.rows_per_split = per; l.splits = (int)((mtot + per - 1) / per);
+            l.slab_stride = (int64_t)N * K + N;
+            l.slab_off = tmp(l.slab_stride * l.splits);
+            const int li = (int)lins.size();
+            lins.push_back(l);
+            op.fwd.push_back(Step{K_LIN_F, li, 1, 0, 0});
+            op.bwd.push_back(Step{K_LIN_W, li, 1, 0, 0});
+            if (xgrad) op.bwd.push_back(Step{K_LIN_A, li, 1, 0, 0});
+            SlabEntry e1{woff, l.slab_off, l.slab_stride, N * K, l.splits}, e2{boff, l.slab_off + (int64_t)N * K, l.slab_stride, N, l.splits};
+            e1.single = e2.single = 1;
+            slabs[stage_idx(stage)].push_back(e1);
+            slabs[stage_idx(stage)].push_back(e2);
+            ops.push_back(op);
+            return out;
+        }
         {
             GemmDesc g{}; g.M = rows; g.N = N; g.K = K; g.ksplit = 1;
             g.A.kind = OPK_DENSE; g.A.space = space; g.A.off = xoff; g.A.si = xld; g.A.sj = 1; g.A.ones_at = -1; g.A.kfast = 1;
@@ -1173,6 +1204,20 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
             else acc_add(v, o.space, o.off, o.slab_stride * g.ksplit, true);
             break;
         }
+        case K_LIN_F: case K_LIN_A: case K_LIN_W: {
+            if (i > 0) break;
+            const LinDesc& l = lins[s.first];
+            const int64_t nx = (int64_t)(l.rows - 1) * l.x_ld + l.K, ny = (int64_t)(l.rows - 1) * l.y_ld + l.N;
+            if (s.kind == K_LIN_F) { acc_add(v, l.x_space, l.x_off, nx, false); acc_add(v, SP_WS, l.y_off, ny, true); }
+            else if (s.kind == K_LIN_W) {
+                acc_add(v, l.x_space, l.x_off, nx, false); acc_add(v, SP_WS, l.y_off, ny, false); acc_add(v, SP_GRAD, l.y_off, ny, false);
+                acc_add(v, SP_TMP, l.slab_off, l.slab_stride * l.splits, true);
+            } else {
+                acc_add(v, SP_WS, l.y_off, ny, false); acc_add(v, SP_GRAD, l.y_off, ny, false);
+                acc_add(v, SP_GRAD, l.x_off, nx, true, true, l.x_ld == l.K || l.rows == 1);
+            }
+            break;
+        }
         case K_CONV_P: case K_CONV_F: case K_CONV_W: {
             if (i > 0) break;
             const ConvDesc& c = convs[s.first];
@@ -1523,6 +1568,7 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
                 else if (!covered(have, a.lo, a.hi)) { Acc z = a; z.space = m.stage; zero.push_back(z); have.push_back(a); }
             }
             if (m.kind == K_COPY_B) this->copies[m.first + q].first = first;
+            if (m.kind == K_LIN_A) this->lins[m.first + q].first[per_stage ? 0 : 1] = first;
             for (int k = 0; k < copies && !plain; ++k) {
                 const int idx = m.first + k * nm + q;
                 if (m.kind == K_GEMM) s_gemms[idx].out.first = first;
@@ -1702,7 +1748,7 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && ((opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64) || opt->gemm_run < 0 || opt->gemm_run > 64)) { *status = MST_ERR_ARG; return nullptr; }
-    if (opt && (opt->lstm_flavour < 0 || opt->lstm_flavour > 2 || opt->reserved[0] || opt->reserved[1])) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && (opt->lstm_flavour < 0 || opt->lstm_flavour > 2 || opt->dense_flavour < 0 || opt->dense_flavour > 2 || opt->reserved[0])) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && (opt->tile_rows < 0 || opt->tile_r0 < 0 || (opt->tile_rows > 0 && (opt->tile_r0 + opt->tile_rows > d->R || d->clips > 1)))) {
         *status = MST_ERR_ARG; return nullptr;
     }
@@ -1790,6 +1836,13 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
     case K_FOLD: return launch_fold(p->d_folds + s.first, 0, b, st);
     case K_SPREAD: return launch_fold(p->d_folds + s.first, 1, b, st);
     case K_XCHG: return MST_ERR_UNSUPPORTED;        // a tiled plan runs through mst_tiled_phase, which stops at exchanges
+    case K_LIN_F: case K_LIN_A: case K_LIN_W: {
+        LinDesc l = p->lins[s.first];
+        l.x_cs = p->shift(l.x_space, 1); l.y_cs = p->act_top; l.gx_cs = p->act_top;
+        if (s.kind == K_LIN_F) return launch_lin_fwd(l, b, st);
+        if (s.kind == K_LIN_W) return launch_lin_dw(l, b, st);
+        return launch_lin_dx(l, b, l.first[(b.flags & MST_BF_ALL_STAGES) ? 1 : 0], st);
+    }
     case K_CONV_P: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_prep(c, b, st); }
     case K_CONV_F: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_fwd(c, b, st); }
     case K_CONV_W: { ConvDesc c = p->convs[s.first]; c.clip_stride = p->act_top; return launch_conv_dw(c, b, st); }
@@ -1806,7 +1859,9 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
 }
 
 // Run one pass (a scheduled list filtered by stage) on the caller's stream.
-static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b, hipStream_t main, bool tags_cleared = false) {
+static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b0, hipStream_t main, bool tags_cleared = false) {
+    Bases b = b0;
+    if (mask == MST_STAGE_ALL) b.flags |= MST_BF_ALL_STAGES;            // p->list(mask, .) is the whole-model list then
     for (auto& s : list) {
         if (!(s.stage & mask)) continue;
         if (tags_cleared && s.kind == K_LSTM_T && p->s_lstms[s.first].multi) continue;      // its only job was the clear
@@ -1928,7 +1983,8 @@ extern "C" int32_t mst_tiled_phase(const mst_plan* p, int32_t phase, const float
         return MST_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const mst_plan::Phase& ph = p->phases[phase];
-    const Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
+    b.flags |= MST_BF_ALL_STAGES;
     const bool U = p->d.has_unpitched != 0;
     float* g = ws + p->act_top;
     auto at = [&](const char* n) { return p->named.at(n).off; };
@@ -1992,6 +2048,13 @@ static void step_cost(const mst_plan* p, const Step& s, double* flops, double* b
     case K_GATHER:
         for (int i = 0; i < s.count; ++i) { const GatherDesc& g = p->s_gathers[s.first + i]; b += 8.0 * g.rows * g.K; }
         break;
+    case K_LIN_F: case K_LIN_A: case K_LIN_W: {
+        const LinDesc& l = p->lins[s.first];
+        const double rows = (double)l.clips * l.rows;
+        f = 2.0 * rows * l.N * l.K;
+        b = 4.0 * (rows * l.K + rows * l.N * (s.kind == K_LIN_F ? 1.0 : 2.0) + (double)l.N * l.K);
+        break;
+    }
     case K_CONV_F: case K_CONV_W: {
         const ConvDesc& c = p->convs[s.first];
         const double rows = (double)c.clips * c.P * NOCT, kk = NF * NPF * CONV_K;
@@ -2069,16 +2132,17 @@ extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t 
 }
 
 // shape of step i of a pass: GEMM {M,N,K,ksplit} of its first descriptor (+count), LSTM {B,S,H,count},
-// segment-reduce {nidx max, width, rows, count}
-extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 5 per step */) {
+// segment-reduce {nidx max, width, rows, count}; then the member count and the step kind
+extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 6 per step */) {
     if (!p || !info) return MST_ERR_ARG;
     std::vector<const Step*> steps;
     for (auto& s : p->list(mask, backward)) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
-        int32_t* o = info + 5 * idx++;
-        o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count;
+        int32_t* o = info + 6 * idx++;
+        o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count; o[5] = s->kind;
         if (s->kind == K_GEMM || s->kind == K_GEMM_FOLD) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
+        else if (s->kind >= K_LIN_F && s->kind <= K_LIN_W) { const LinDesc& l = p->lins[s->first]; o[0] = l.rows; o[1] = l.N; o[2] = l.K; o[3] = l.splits; }
         else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; o[3] = l.multi; }
         else if (s->kind == K_GATHER) { const GatherDesc& g = p->s_gathers[s->first]; o[0] = g.rows; o[1] = g.K; o[2] = g.nseg; }
         else if (s->kind == K_SEGRED) { const SegRedDesc& r = p->s_segreds[s->first]; o[0] = s->a; o[1] = r.width; o[2] = r.d[0] * r.d[1] * r.d[2] * r.d[3]; }
@@ -2113,6 +2177,7 @@ extern "C" int32_t mst_plan_time_steps(const mst_plan* p, int32_t mask, int32_t 
     hipStream_t st = (hipStream_t)stream;
     Bases b = make_bases(p, params, gparams, ws, pitched, unpitched);
     if (backward && !p->tiled()) b.flags = MST_BF_LOSS_FUSED;          // what mst_train_iteration launches
+    if ((mask & MST_STAGE_ALL) == MST_STAGE_ALL) b.flags |= MST_BF_ALL_STAGES;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MST_ERR_ALLOC;
     std::vector<const Step*> steps;

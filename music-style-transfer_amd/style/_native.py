@@ -40,7 +40,7 @@ class Dims(C.Structure):
 
 class PlanOptions(C.Structure):
     _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('tile_r0', C.c_int32),
-                ('tile_rows', C.c_int32), ('lstm_flavour', C.c_int32), ('reserved', C.c_int32 * 2)]
+                ('tile_rows', C.c_int32), ('lstm_flavour', C.c_int32), ('dense_flavour', C.c_int32), ('reserved', C.c_int32 * 1)]
 
 
 DEV_LSTM_TIMEOUT = 1        # mst_amd.h MST_DEV_LSTM_TIMEOUT
@@ -65,7 +65,8 @@ def options_from_env():
     if ge not in (None, '', 'mfma', 'valu'):
         raise MstError(f'MST_GEMM={ge!r}: expected mfma or valu')
     return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))),
-                gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')), lstm_flavour=int(os.environ.get('MST_LSTM_FLAVOUR', '0')))
+                gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')), lstm_flavour=int(os.environ.get('MST_LSTM_FLAVOUR', '0')),
+                dense_flavour=int(os.environ.get('MST_DENSE_FLAVOUR', '0')))
 
 
 _P = C.c_void_p
@@ -187,13 +188,14 @@ class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
     WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0, lstm_flavour=None):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0, lstm_flavour=None, dense_flavour=None):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
         env = options_from_env()
         opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
                            no_merge=env['no_merge'] if no_merge is None else int(no_merge),
                            gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run), tile_r0=int(tile_r0), tile_rows=int(tile_rows),
-                           lstm_flavour=env['lstm_flavour'] if lstm_flavour is None else int(lstm_flavour))
+                           lstm_flavour=env['lstm_flavour'] if lstm_flavour is None else int(lstm_flavour),
+                           dense_flavour=env['dense_flavour'] if dense_flavour is None else int(dense_flavour))
         st = C.c_int32()
         self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:

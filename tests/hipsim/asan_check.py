@@ -19,20 +19,21 @@ class Dims(C.Structure):
                                          'instr', 'n_instruments', 'has_unpitched', 'clips')]
 
 
-lib.mst_plan_create.restype = C.c_void_p
+class Opts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('gemm_tile', 'no_merge', 'gemm_run', 'tile_r0', 'tile_rows', 'lstm_flavour', 'dense_flavour', 'reserved')]
+
+
+lib.mst_plan_create_ex.restype = C.c_void_p
 lib.mst_plan_workspace_floats.restype = C.c_int64
 lib.mst_param_floats.restype = C.c_int64
 P = C.c_void_p
 
 
-def run(C_, R, T, widths, unp, clips=1, gemm=None):
-    if gemm:
-        os.environ['MST_GEMM'] = gemm
-    else:
-        os.environ.pop('MST_GEMM', None)
+def run(C_, R, T, widths, unp, clips=1, gemm=None, dense=0):
     d = Dims(C_, R, T, *widths, 51, 41, int(unp), clips)
     st = C.c_int32()
-    plan = C.c_void_p(lib.mst_plan_create(C.byref(d), C.byref(st)))
+    o = Opts(gemm_tile={None: 0, 'mfma': 64, 'valu': 32}[gemm], dense_flavour=dense)
+    plan = C.c_void_p(lib.mst_plan_create_ex(C.byref(d), C.byref(o), C.byref(st)))
     assert plan.value, st.value
     n = lib.mst_param_floats(C.byref(d))
     rng = np.random.default_rng(0)
@@ -49,7 +50,7 @@ def run(C_, R, T, widths, unp, clips=1, gemm=None):
     lib.mst_adam_step.argtypes = [P, P, P, P, C.c_int64, P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_int32, P]
     assert lib.mst_adam_step(a(params), a(g), a(m), a(v), n, a(state), .01, .9, .999, 1e-8, 200, .9, 1, None) == 0
     lib.mst_plan_destroy(plan)
-    print('ok', (C_, R, T), widths, unp, 'clips', clips, gemm or 'default gemm', 'total loss', float(losses[0]), 'finite grads', bool(np.isfinite(params).all()))
+    print('ok', (C_, R, T), widths, unp, 'clips', clips, gemm or 'default gemm', 'dense', dense, 'total loss', float(losses[0]), 'finite grads', bool(np.isfinite(params).all()))
 
 
 # (every MFMA of the emulated GEMMs is two fiber round trips per lane: shapes are kept tiny so the pass takes minutes)
@@ -60,4 +61,6 @@ run(1, 3, 1, (64, 128, 8, 256, 8, 32), False)                      # three bars:
 run(1, 2, 1, (8, 6, 3, 12, 4, 6), True, clips=3)                    # batched plan, 32x32 GEMM tiling
 run(2, 1, 1, (8, 6, 3, 12, 4, 6), True, clips=2, gemm='mfma')       # batched plan on the 64x64 GEMM tiling
 run(1, 1, 2, (64, 128, 8, 256, 8, 32), False, gemm='mfma')          # one clip, full widths, 64x64 tiling
+run(2, 1, 1, (8, 6, 3, 12, 4, 6), True, clips=3, gemm='mfma', dense=2)   # lin.hip's kernels on every eligible Linear, ragged row totals
+run(1, 1, 1, (64, 128, 8, 256, 8, 32), True, gemm='mfma', dense=2)       # ... at full widths (K = 514, 280, 82; N = 16 .. 376)
 print('asan pass clean')

@@ -315,6 +315,7 @@ static inline int hipsim_fetch_or(int* p, int v) { int o = *p; *p = o | v; retur
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline void __builtin_amdgcn_s_sleep(int) { hipsim::spin_yield(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline long long wall_clock64() { static long long t = 0; hipsim::st().progress++; return ++t; }
 static inline void __threadfence() {}
 

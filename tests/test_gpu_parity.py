@@ -62,6 +62,13 @@ def test_batched_clips_full_widths(native, K, tile):
     pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, K, gemm_tile=tile)
 
 
+def test_large_linear_kernels_on_every_eligible_layer(native):
+    # lin.hip (2 x 2-blocked MFMA tiles, all clips as rows of one launch) takes the large Linears (>= 512 rows, >= 4 MFLOP per clip) of the bench plans (the two
+    # tests below); dense_flavour = 2 sends every eligible Linear there: ragged row totals, N from 16 to 376, K from 4 to 514
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, 5, gemm_tile=64, dense_flavour=2)
+    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 7, 3, 3, True, gemm_tile=64, dense_flavour=2)
+
+
 def test_batched_32_bench_clips_configs3_per_gpu_share(native):
     # BASELINE.json configs[3]: minibatch 256 over 8 GPUs = 32 x (C=4, R=16, T=4) clips per GPU in one plan; against the
     # oracle clip by clip (outputs, 15 loss leaves per clip, summed gradient) and against 32 one-clip iterations bit for bit

@@ -32,6 +32,34 @@ def test_batched_plan_folds_the_clips_into_its_weight_gradient_gemms():
     assert all(m[4] == 0 for m in gemm_members(one, True))
 
 
+def step_rows(plan, backward, mask=7):
+    import numpy as np
+    n = plan.lib.mst_plan_step_count(plan.handle, mask, int(backward))
+    info = np.zeros((n, 6), np.int32)
+    assert plan.lib.mst_plan_step_info(plan.handle, mask, int(backward), info.ctypes.data) == n
+    return info.tolist()
+
+
+def test_batched_plan_runs_its_large_linears_on_the_blocked_tiles():
+    # 64 clips, 7 instruments: every large Linear (>= 512 rows, >= 4 MFLOP per clip, more than 32 outputs: the applier's 800-row
+    # layers, the 560-row K = 514 / 112 ones) is a lin.hip step (kinds 29-31) with all clips as rows of one launch; a one-clip
+    # plan on the default (32x32) tiling has none, and dense_flavour = 1 opts out
+    native = sim_native()
+    dims = pc.make_dims(pc.FULL, 7, 8, 10, True)
+    dims.clips = 64
+    plan = nat.Plan(native, dims, 'cpu')
+    fwd = [r for r in step_rows(plan, False) if r[5] == 29]
+    bwd = [r for r in step_rows(plan, True) if r[5] in (30, 31)]
+    assert fwd and bwd
+    for rows, N, K, splits, count, kind in fwd + bwd:
+        assert rows >= 512 and N > 32 and 2.0 * rows * N * K >= 4e6
+    assert len([r for r in bwd if r[5] == 31]) == len(fwd)               # one weight-gradient launch per forward launch
+    off = nat.Plan(native, dims, 'cpu', dense_flavour=1)
+    assert not [r for r in step_rows(off, False) + step_rows(off, True) if r[5] in (29, 30, 31)]
+    one = nat.Plan(native, pc.make_dims(pc.FULL, 7, 8, 10, True), 'cpu')
+    assert not [r for r in step_rows(one, False) + step_rows(one, True) if r[5] in (29, 30, 31)]
+
+
 def test_rhythm_encoder_linear_never_sees_the_135_wide_concat():
     # pitched rhythm encoder (full widths): cat_with_broadcast of six segments, 135 columns in all, feeding a Linear to 32.
     # Decomposed (linear_bcast), the only full-row GEMM of that Linear has K = 16 (the per-fraction channels block);

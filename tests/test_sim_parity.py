@@ -60,6 +60,15 @@ def test_mfma_gemm_runs_of_several_tiles_per_workgroup():
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4, gemm_tile=64, gemm_run=2)
 
 
+def test_large_linear_kernels_at_small_sizes():
+    # lin.hip serves the large nn.Linear layers (>= 512 rows and >= 4 MFLOP per clip) of plans on the 64x64 tiling; dense_flavour = 2 sends every eligible
+    # layer there: one clip against the oracle (every tensor, every parameter gradient), then ragged clip counts whose row
+    # total is not a multiple of the 64/128/256-row tiles and whose weight-gradient row splits cross clip boundaries
+    pc.oracle_case(sim_native(), 'cpu', pc.FULL, 2, 3, 2, True, density=0.03, gemm_tile=64, dense_flavour=2)
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 2, 2, 1, True, 4, gemm_tile=64, dense_flavour=2)
+    pc.batch_case(sim_native(), 'cpu', pc.SMALL, 3, 3, 1, True, 3, gemm_tile=64, dense_flavour=2)
+
+
 def test_single_clip_on_the_mfma_gemm(monkeypatch):
     monkeypatch.setenv('MST_GEMM', 'mfma')
     pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True)
