@@ -90,7 +90,12 @@ typedef struct {
     int32_t dense_flavour;      /* large dense nn.Linear layers of plans on the 64x64 tiling (lin.hip: all clips as rows of one launch, 2 x 2-blocked
                                  * MFMA tiles): 0 = choose (layers of >= 512 rows and >= 4 MFLOP per clip with more than 32 outputs), 1 = never, 2 = every eligible layer (parity tests
                                  * at small sizes) */
-    int32_t reserved[1];        /* must be 0 */
+    int32_t branches;           /* 1 = spread the launches of the whole-model passes over the caller's stream + 3 side streams along the dependency
+                                 * DAG (event waits where a dependency crosses streams); 0 = one stream (default).  An experiment that LOST on
+                                 * MI355X (ROCm 7.2), kept for the record and for its parity test: one bench clip, eager launches 0.85 ms per
+                                 * step against 0.49; a replayed hipGraph 875 us per iteration against 812 (a graph with parallel branches pays
+                                 * ~5 us per node boundary and per cross edge, a single chain ~2 us per boundary: tools/probe/capture_probe.cpp);
+                                 * torch.cuda.graph's capture_end crashes on such captures, so the Python binding refuses them. */
 } mst_plan_options;
 mst_plan* mst_plan_create(const mst_dims* d, int32_t* status);                       /* default options */
 mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_options* opt, int32_t* status);
@@ -203,7 +208,7 @@ int32_t mst_hard_output(float* x, float* out, int64_t n_pos, int32_t nfeat, mst_
  * 11 lstm weight transpose, 12/13 row-wise tiny Linear fwd/bwd, ..., 26-28 conv.hip prep / forward / weight gradient,
  * 29-31 lin.hip forward / input gradient / weight gradient. */
 int32_t mst_plan_step_count(const mst_plan* p, int32_t stage_mask, int32_t backward);
-int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 6 ints per step: 4 shape values, member count, kind */);
+int32_t mst_plan_step_info(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t* info /* 8 ints per step: 4 shape values, member count, kind, dependency level (inside its chain), chain (-1 = none) */);
 /* (new) instrumentation: the members of GEMM launch step `step` of a pass, one clip's worth, 6 values each:
  * {M, N, K, k-splits, folded rows per clip (0 = not folded), workgroups}.  Returns the member count (<= cap). */
 int32_t mst_plan_step_gemms(const mst_plan* p, int32_t stage_mask, int32_t backward, int32_t step, int32_t* out, int32_t cap);

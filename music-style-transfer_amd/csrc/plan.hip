@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "mst_common.h"
@@ -202,7 +203,9 @@ enum { K_GEMM, K_GATHER, K_SEGRED, K_LSTM_F, K_LSTM_B, K_COMB_F, K_COMB_B, K_ME_
        K_GEMM_FOLD,        // weight-gradient GEMMs of a batched plan with the clips folded into K (one descriptor for all clips)
        K_CONV_P, K_CONV_F, K_CONV_W,
        K_LIN_F, K_LIN_A, K_LIN_W };     // ... and its large dense nn.Linear layers (lin.hip): forward, input gradient, weight gradient      // batched plans on the 64x64 tiling: the note-axis convolution on its own kernels (conv.hip), one descriptor for all clips
-struct Step { int kind, first, count, a, b, stage; int c = 0; int lvl = 0; };      // c: GEMM steps — offset of the step's block -> member table; lvl: dependency level in its scheduled pass
+struct Step { int kind, first, count, a, b, stage; int c = 0; int lvl = 0; int chain = -1; int signal = -1; int wait[3] = {-1, -1, -1}; };
+// c: GEMM steps — offset of the step's block -> member table; lvl: dependency level in its scheduled pass; chain / signal / wait: the stream the
+// launch goes to, the event slot recorded behind it and the slots its stream waits for in front of it (assign_streams; chain -1 = caller's stream)
 struct Acc { int space; int64_t lo, hi; bool w; bool accum = false, dense = true; };   // accum: a += writer; dense: covers [lo, hi) fully
 struct Op { int stage; std::vector<Step> fwd, bwd; };
 
@@ -278,6 +281,31 @@ struct mst_plan {
         return per_cu > 1 ? (per_cu - 1) * device_cus() : 0;
     }
     int64_t status_off = 0;            // [SP_WS, clip 0] device status word ("device_status")
+    // side streams of run_pass (mst_plan_options.branches): same-level launches fork from / join to the caller's stream
+    // The launches of such plans' whole-model lists are spread over 1 + N_SIDE streams along the dependency DAG (assign_streams);
+    // a set of side streams / events belongs to ONE caller stream (two accumulation iterations captured side by side must not
+    // meet in a shared side stream), created at the caller's first (eager) pass.
+    enum { N_SIDE = 3, N_SETS = 4, N_EVENTS = 96 };
+    struct SideSet { hipStream_t owner = nullptr; bool used = false; hipStream_t side[N_SIDE] = {}; hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {}, ev[N_EVENTS] = {}; };
+    mutable SideSet sides[N_SETS];
+    bool branches = false;
+    SideSet* side_set(hipStream_t main) const {
+        for (SideSet& q : sides) if (q.used && q.owner == main) return &q;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // no object creation inside a capture
+        for (SideSet& q : sides) {
+            if (q.used) continue;
+            bool ok = hipEventCreateWithFlags(&q.ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < N_SIDE; ++i)
+                ok = ok && hipStreamCreateWithFlags(&q.side[i], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&q.ev_join[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < n_signals; ++i) ok = ok && hipEventCreateWithFlags(&q.ev[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) return nullptr;
+            q.used = true; q.owner = main;
+            return &q;
+        }
+        return nullptr;                 // more caller streams than sets: that caller runs its chains back to back
+    }
     int64_t ext0_stride() const { return (int64_t)P() * NF * NPN * NPF; }
     int64_t ext1_stride() const { return (int64_t)Q() * NF * NUN * NUF; }
     // offset of clip k's slice of `space` relative to clip 0's
@@ -451,7 +479,7 @@ struct mst_plan {
             l.x_space = space; l.x_ld = xld; l.x_off = xoff; l.y_ld = out.ld; l.y_off = out.off; l.w_off = woff; l.b_off = boff;
             const int64_t mtot = (int64_t)this->K() * rows;
             const int tl = lin_dw_tiles(l);
-            int64_t sp = std::max<int64_t>(1, 512 / tl);
+            int64_t sp = std::max<int64_t>(1, 768 / tl);       // three workgroups per CU, all co-resident
             int64_t per = ((mtot + sp - 1) / sp + 31) / 32 * 32;
             if (per < 128) per = 128;
             l.rows_per_split = per; l.splits = (int)((mtot + per - 1) / per);
@@ -528,7 +556,7 @@ struct mst_plan {
             ConvDesc c{}; c.P = P_; c.clips = this->K(); c.OC = z.OC; c.x1_off = x1.off; c.w_off = woff; c.b_off = boff;
             c.wp_off = tmp((int64_t)NF * 72 * 64);
             const int64_t rows = (int64_t)this->K() * P_ * NOCT;
-            int64_t sp = 170;                                 // 3 column tiles x 170 splits = 510 workgroups: two rounds of the chip
+            int64_t sp = 256;                                 // 3 column tiles x 256 splits = 768 workgroups: three per CU, all co-resident (166 VGPRs)
             int64_t per = ((rows + sp - 1) / sp + 31) / 32 * 32;
             if (per < 256) per = 256;
             c.rows_per_split = per; c.splits = (int)((rows + per - 1) / per);
@@ -868,6 +896,8 @@ struct mst_plan {
     void accesses(const Step& s, std::vector<Acc>& out, bool scheduled = false) const;
     void first_writers(std::vector<Step>& list, size_t begin, bool per_stage, std::vector<Acc>& zero);
     void schedule_pass(const std::vector<Step>& seq, std::vector<Step>& out, bool across_stages);
+    bool assign_streams(std::vector<Step>& L);
+    int n_signals = 0;                 // event slots assign_streams handed out (<= N_EVENTS)
     void schedule();
     int upload();
 };
@@ -1580,6 +1610,69 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
     }
 }
 
+// Spread the launches of a scheduled whole-model list over 1 + N_SIDE streams along its dependency DAG (list scheduling): a
+// launch depends on every earlier launch it shares memory with (any overlap with a write on either side: conflicts()).  In list
+// order, each launch goes to the stream where it can start first under a simple cost model (a launch on the stream of the
+// predecessor it waits for longest starts right behind it; a dependency that crosses streams costs an event wait, measured
+// ~5 us per edge inside a replayed hipGraph against ~2 us for a same-stream boundary — so the model is reluctant to cross).
+// Cross-stream dependencies become (signal, wait) pairs: the producer records an event slot behind it, the consumer's stream
+// waits for it; waits already implied by stream order or by an earlier wait are dropped (vector clocks).  The result is checked:
+// every conflicting pair must be ordered by stream order and waits, else the plan keeps one stream.
+bool mst_plan::assign_streams(std::vector<Step>& L) {
+    const int n = (int)L.size(), NS = 1 + N_SIDE;
+    std::vector<std::vector<Acc>> acc(n);
+    for (int i = 0; i < n; ++i) accesses(L[i], acc[i], true);
+    auto dur = [&](const Step& st) {           // rough one-clip durations in us (profiles/: pass_timeline_one_clip)
+        switch (st.kind) {
+        case K_LSTM_F: case K_LSTM_B: return s_lstms[st.first].multi ? 30.0 : 15.0;
+        case K_ME_F: case K_ME_B: case K_PSA_F: case K_PSA_B: return 18.0;
+        case K_GEMM: case K_GEMM_FOLD: return st.count > 8 ? 10.0 : 5.0;
+        case K_SEGRED: return 9.0;
+        default: return 5.0;
+        }
+    };
+    const double EDGE_IN = 2.0, EDGE_X = 6.0;
+    std::vector<double> fin(n, 0.0);
+    std::vector<int> str(n, 0);
+    double ready[1 + N_SIDE] = {};
+    // clock[i][r]: the latest launch index on stream r known to be complete when launch i starts (through stream order and waits)
+    std::vector<std::array<int, 1 + N_SIDE>> clock(n);
+    int tail[1 + N_SIDE]; for (int q = 0; q < NS; ++q) tail[q] = -1;
+    for (int i = 0; i < n; ++i) {
+        std::vector<int> preds;
+        for (int j = 0; j < i; ++j) if (conflicts(acc[i], acc[j])) preds.push_back(j);
+        int best = 0; double best_start = 1e30;
+        for (int q = 0; q < NS; ++q) {
+            double start = ready[q];
+            for (int j : preds) start = std::max(start, fin[j] + (str[j] == q ? 0.0 : EDGE_X));
+            if (start < best_start - 1e-9) { best_start = start; best = q; }
+        }
+        const int q = best;
+        str[i] = q; L[i].chain = q;
+        fin[i] = best_start + dur(L[i]) + EDGE_IN; ready[q] = fin[i];
+        // what is known complete when i starts: its stream's tail (and what that knew), then the waits
+        std::array<int, 1 + N_SIDE> ck; ck.fill(-1);
+        if (tail[q] >= 0) { ck = clock[tail[q]]; ck[q] = tail[q]; }
+        int need[1 + N_SIDE]; for (int r = 0; r < NS; ++r) need[r] = -1;
+        for (int j : preds) if (str[j] != q && j > ck[str[j]]) need[str[j]] = std::max(need[str[j]], j);
+        int nw = 0;
+        for (int r = 0; r < NS; ++r) {
+            if (need[r] < 0) continue;
+            const int j = need[r];
+            if (L[j].signal < 0) { if (n_signals >= N_EVENTS) return false; L[j].signal = n_signals++; }
+            L[i].wait[nw++] = L[j].signal;
+            for (int t = 0; t < NS; ++t) ck[t] = std::max(ck[t], clock[j][t]);
+            ck[r] = std::max(ck[r], j);
+        }
+        clock[i] = ck; tail[q] = i;
+    }
+    // check: every conflicting pair (j < i) is ordered
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (conflicts(acc[i], acc[j]) && !(str[j] == str[i] || clock[i][str[j]] >= j)) return false;
+    return true;
+}
+
 void mst_plan::schedule() {
     // Two GEMM tilings, both on v_mfma_f32_32x32x2_f32: few clips per launch are latency-bound and want many small
     // workgroups with a short k chain (32x32 tiles, 16 waves split the k-tile); from about six clips per launch on
@@ -1591,11 +1684,17 @@ void mst_plan::schedule() {
     for (size_t i = ops.size(); i-- > 0;) for (auto s : ops[i].bwd) { s.stage = ops[i].stage; bwd.push_back(s); }
     schedule_pass(fwd, sched[0], false);
     schedule_pass(bwd, sched[1], false);
+    // mst_plan_options.branches: the whole-model lists' launches are spread over streams along the dependency DAG
+    branches = opt.branches == 1 && !tiled();
     schedule_pass(fwd, sched_all[0], true);
     schedule_pass(bwd, sched_all[1], true);
     std::vector<Acc> zs, za;
     first_writers(sched[1], 0, true, zs);
     first_writers(sched_all[1], 0, false, za);
+    if (branches && !(assign_streams(sched_all[0]) && assign_streams(sched_all[1]))) {
+        branches = false;
+        for (int ps = 0; ps < 2; ++ps) for (Step& st : sched_all[ps]) { st.chain = -1; st.signal = -1; st.wait[0] = st.wait[1] = st.wait[2] = -1; }
+    }
     // zero lists -> chunks of <= 16 K floats (one workgroup each); Acc.space carries the stage of the step that needs it
     auto chunks = [&](const std::vector<Acc>& z, int stage_mask, std::vector<ZeroChunk>& out) {
         for (const Acc& a : z) {
@@ -1748,7 +1847,7 @@ extern "C" mst_plan* mst_plan_create_ex(const mst_dims* d, const mst_plan_option
     int32_t dummy; if (!status) status = &dummy;
     if (!dims_ok(d)) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && ((opt->gemm_tile != 0 && opt->gemm_tile != 32 && opt->gemm_tile != 64) || opt->gemm_run < 0 || opt->gemm_run > 64)) { *status = MST_ERR_ARG; return nullptr; }
-    if (opt && (opt->lstm_flavour < 0 || opt->lstm_flavour > 2 || opt->dense_flavour < 0 || opt->dense_flavour > 2 || opt->reserved[0])) { *status = MST_ERR_ARG; return nullptr; }
+    if (opt && (opt->lstm_flavour < 0 || opt->lstm_flavour > 2 || opt->dense_flavour < 0 || opt->dense_flavour > 2 || opt->branches < 0 || opt->branches > 1)) { *status = MST_ERR_ARG; return nullptr; }
     if (opt && (opt->tile_rows < 0 || opt->tile_r0 < 0 || (opt->tile_rows > 0 && (opt->tile_r0 + opt->tile_rows > d->R || d->clips > 1)))) {
         *status = MST_ERR_ARG; return nullptr;
     }
@@ -1773,6 +1872,11 @@ extern "C" void mst_plan_destroy(mst_plan* p) {
     hipFree(p->d_gemms); hipFree(p->d_gathers); hipFree(p->d_segreds); hipFree(p->d_lstms); hipFree(p->d_combines); hipFree(p->d_notes);
     for (int s = 0; s < 3; ++s) { hipFree(p->d_slabs[s]); hipFree(p->d_slab_blocks[s]); }
     hipFree(p->d_slabs_all); hipFree(p->d_slab_blocks_all);
+    for (mst_plan::SideSet& q : p->sides) {
+        if (q.ev_fork) hipEventDestroy(q.ev_fork);
+        for (int i = 0; i < mst_plan::N_SIDE; ++i) { if (q.ev_join[i]) hipEventDestroy(q.ev_join[i]); if (q.side[i]) hipStreamDestroy(q.side[i]); }
+        for (hipEvent_t e : q.ev) if (e) hipEventDestroy(e);
+    }
     delete p;
 }
 
@@ -1862,12 +1966,36 @@ static int run_step(const mst_plan* p, const Step& s, const Bases& b, hipStream_
 static int run_pass(const mst_plan* p, const std::vector<Step>& list, int mask, const Bases& b0, hipStream_t main, bool tags_cleared = false) {
     Bases b = b0;
     if (mask == MST_STAGE_ALL) b.flags |= MST_BF_ALL_STAGES;            // p->list(mask, .) is the whole-model list then
+    auto runs = [&](const Step& s) {
+        if (!(s.stage & mask)) return false;
+        if (tags_cleared && s.kind == K_LSTM_T && p->s_lstms[s.first].multi) return false;     // its only job was the clear
+        return true;
+    };
+    // Streams (plans with `branches`, whole-model lists): launch s goes to stream s.chain (0 = the caller's, c = side stream c - 1)
+    // behind the waits assign_streams gave it; a side stream's first launch of the pass also waits for the caller's stream (fork),
+    // and the caller's stream waits for every side stream at the end (join) — parallel branches once captured into a hipGraph.
+    mst_plan::SideSet* ss = (p->branches && mask == MST_STAGE_ALL) ? p->side_set(main) : nullptr;
+    bool forked = false, used[mst_plan::N_SIDE] = {};
     for (auto& s : list) {
-        if (!(s.stage & mask)) continue;
-        if (tags_cleared && s.kind == K_LSTM_T && p->s_lstms[s.first].multi) continue;      // its only job was the clear
-        int e = run_step(p, s, b, main);
+        if (!runs(s)) continue;
+        hipStream_t st = main;
+        if (ss) {
+            if (s.chain > 0) {
+                const int c = s.chain - 1;
+                if (!forked) { if (hipEventRecord(ss->ev_fork, main) != hipSuccess) return MST_ERR_LAUNCH; forked = true; }
+                if (!used[c]) { if (hipStreamWaitEvent(ss->side[c], ss->ev_fork, 0) != hipSuccess) return MST_ERR_LAUNCH; used[c] = true; }
+                st = ss->side[c];
+            }
+            for (int w = 0; w < 3; ++w)
+                if (s.wait[w] >= 0 && hipStreamWaitEvent(st, ss->ev[s.wait[w]], 0) != hipSuccess) return MST_ERR_LAUNCH;
+        }
+        int e = run_step(p, s, b, st);
         if (e) return e < 0 ? e : MST_ERR_LAUNCH;
+        if (ss && s.signal >= 0 && hipEventRecord(ss->ev[s.signal], st) != hipSuccess) return MST_ERR_LAUNCH;
     }
+    if (ss)
+        for (int c = 0; c < mst_plan::N_SIDE; ++c)
+            if (used[c] && (hipEventRecord(ss->ev_join[c], ss->side[c]) != hipSuccess || hipStreamWaitEvent(main, ss->ev_join[c], 0) != hipSuccess)) return MST_ERR_LAUNCH;
     return MST_OK;
 }
 
@@ -2132,15 +2260,15 @@ extern "C" int32_t mst_plan_step_count(const mst_plan* p, int32_t mask, int32_t 
 }
 
 // shape of step i of a pass: GEMM {M,N,K,ksplit} of its first descriptor (+count), LSTM {B,S,H,count},
-// segment-reduce {nidx max, width, rows, count}; then the member count and the step kind
-extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 6 per step */) {
+// segment-reduce {nidx max, width, rows, count}; then the member count, the step kind, its dependency level and its chain (-1: none)
+extern "C" int32_t mst_plan_step_info(const mst_plan* p, int32_t mask, int32_t backward, int32_t* info /* 8 per step */) {
     if (!p || !info) return MST_ERR_ARG;
     std::vector<const Step*> steps;
     for (auto& s : p->list(mask, backward)) if (s.stage & mask) steps.push_back(&s);
     int idx = 0;
     for (const Step* s : steps) {
-        int32_t* o = info + 6 * idx++;
-        o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count; o[5] = s->kind;
+        int32_t* o = info + 8 * idx++;
+        o[0] = o[1] = o[2] = o[3] = 0; o[4] = s->count; o[5] = s->kind; o[6] = s->lvl; o[7] = s->chain;
         if (s->kind == K_GEMM || s->kind == K_GEMM_FOLD) { const GemmDesc& g = p->s_gemms[s->first]; o[0] = g.M; o[1] = g.N; o[2] = g.K; o[3] = g.ksplit; }
         else if (s->kind >= K_LIN_F && s->kind <= K_LIN_W) { const LinDesc& l = p->lins[s->first]; o[0] = l.rows; o[1] = l.N; o[2] = l.K; o[3] = l.splits; }
         else if (s->kind == K_LSTM_F || s->kind == K_LSTM_B) { const LstmDesc& l = p->s_lstms[s->first]; o[0] = l.B; o[1] = l.S; o[2] = l.H; o[3] = l.multi; }

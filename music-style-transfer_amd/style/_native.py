@@ -40,7 +40,7 @@ class Dims(C.Structure):
 
 class PlanOptions(C.Structure):
     _fields_ = [('gemm_tile', C.c_int32), ('no_merge', C.c_int32), ('gemm_run', C.c_int32), ('tile_r0', C.c_int32),
-                ('tile_rows', C.c_int32), ('lstm_flavour', C.c_int32), ('dense_flavour', C.c_int32), ('reserved', C.c_int32 * 1)]
+                ('tile_rows', C.c_int32), ('lstm_flavour', C.c_int32), ('dense_flavour', C.c_int32), ('branches', C.c_int32)]
 
 
 DEV_LSTM_TIMEOUT = 1        # mst_amd.h MST_DEV_LSTM_TIMEOUT
@@ -60,13 +60,14 @@ def describe_status(word):
 def options_from_env():
     """Developer switches of the Python binding; the C library itself reads no environment.
     MST_GEMM=mfma|valu forces the 64x64 / 32x32 GEMM tiling, MST_NO_MERGE=1 gives one launch per scheduled member,
-    MST_LSTM_FLAVOUR=1 keeps the H = 192 LSTM on one workgroup per sequence (mst_plan_options.lstm_flavour)."""
+    MST_LSTM_FLAVOUR=1 keeps the H = 192 LSTM on one workgroup per sequence (mst_plan_options.lstm_flavour),
+    MST_DENSE_FLAVOUR / MST_BRANCHES set mst_plan_options.dense_flavour / .branches."""
     ge = os.environ.get('MST_GEMM')
     if ge not in (None, '', 'mfma', 'valu'):
         raise MstError(f'MST_GEMM={ge!r}: expected mfma or valu')
     return dict(gemm_tile={'mfma': 64, 'valu': 32}.get(ge, 0), no_merge=int(bool(os.environ.get('MST_NO_MERGE'))),
                 gemm_run=int(os.environ.get('MST_GEMM_RUN', '0')), lstm_flavour=int(os.environ.get('MST_LSTM_FLAVOUR', '0')),
-                dense_flavour=int(os.environ.get('MST_DENSE_FLAVOUR', '0')))
+                dense_flavour=int(os.environ.get('MST_DENSE_FLAVOUR', '0')), branches=int(os.environ.get('MST_BRANCHES', '0')))
 
 
 _P = C.c_void_p
@@ -188,19 +189,21 @@ class Plan:
     """One mst_plan + its workspace tensor. Tensors returned by `view`/`grad` alias the workspace."""
     WS_POOL_CAP = 4
 
-    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0, lstm_flavour=None, dense_flavour=None):
+    def __init__(self, native, dims, device, gemm_tile=None, no_merge=None, gemm_run=None, tile_r0=0, tile_rows=0, lstm_flavour=None, dense_flavour=None, branches=None):
         self.native, self.lib, self.dims, self.device = native, native.lib, dims, torch.device(device)
         env = options_from_env()
         opts = PlanOptions(gemm_tile=env['gemm_tile'] if gemm_tile is None else gemm_tile,
                            no_merge=env['no_merge'] if no_merge is None else int(no_merge),
                            gemm_run=env['gemm_run'] if gemm_run is None else int(gemm_run), tile_r0=int(tile_r0), tile_rows=int(tile_rows),
                            lstm_flavour=env['lstm_flavour'] if lstm_flavour is None else int(lstm_flavour),
-                           dense_flavour=env['dense_flavour'] if dense_flavour is None else int(dense_flavour))
+                           dense_flavour=env['dense_flavour'] if dense_flavour is None else int(dense_flavour),
+                           branches=env['branches'] if branches is None else int(branches))
         st = C.c_int32()
         self.handle = self.lib.mst_plan_create_ex(C.byref(dims), C.byref(opts), C.byref(st))
         if not self.handle:
             check(st.value or -1, 'mst_plan_create_ex')
         self.gemm_tile = self.lib.mst_plan_gemm_tile(self.handle)
+        self.branches = bool(opts.branches)
         n = self.lib.mst_plan_workspace_floats(self.handle)
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)
         self._free_ws = []
@@ -270,6 +273,9 @@ class Plan:
             raise MstError('device status: ' + describe_status(word))
 
     def _touch(self, ws):
+        if self.branches and self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            # torch.cuda.graph's capture_end crashes on a capture that forks into this plan's side streams (ROCm 7.2, torch 2.10)
+            raise MstError('a plan made with branches=1 cannot run under torch.cuda.graph capture; capture needs branches=0')
         ws = self.ws if ws is None else ws
         self._touched[id(ws)] = ws
         return ws

@@ -20,7 +20,7 @@ class Dims(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('gemm_tile', 'no_merge', 'gemm_run', 'tile_r0', 'tile_rows', 'lstm_flavour', 'dense_flavour', 'reserved')]
+    _fields_ = [(n, C.c_int32) for n in ('gemm_tile', 'no_merge', 'gemm_run', 'tile_r0', 'tile_rows', 'lstm_flavour', 'dense_flavour', 'branches')]
 
 
 lib.mst_plan_create_ex.restype = C.c_void_p

@@ -157,7 +157,7 @@ def oracle_case(native, device, widths, C, R, T, unp, seed=0, clip_id=5, density
     return e, worst
 
 
-def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True, gemm_tile=None, gemm_run=None, dense_flavour=None):
+def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, check_oracle=True, gemm_tile=None, gemm_run=None, dense_flavour=None, branches=None):
     """K different clips in ONE plan (mst_dims.clips = K) against (a) the oracle run clip by clip with
     gradients accumulating like train-model.py:126 and (b) the product's own one-clip plan run K times:
     per-clip activations and losses are bit-identical; the summed gradient is equal to rounding (the order in
@@ -166,8 +166,8 @@ def batch_case(native, device, widths, C, R, T, unp, K, seed=0, density=0.03, ch
     dimsK = make_dims(widths, C, R, T, unp, clips=K)
     # a plan picks its GEMM tiling from the clip count (K >= 6: 64x64 tiles, else 32x32 split-K) unless `gemm_tile` forces
     # one; the bitwise comparison needs the one-clip plan on the tiling the batched plan chose
-    planK = nat.Plan(native, dimsK, device, gemm_tile=gemm_tile, gemm_run=gemm_run, dense_flavour=dense_flavour)
-    plan1 = nat.Plan(native, dims1, device, gemm_tile=planK.gemm_tile, gemm_run=gemm_run, dense_flavour=dense_flavour)
+    planK = nat.Plan(native, dimsK, device, gemm_tile=gemm_tile, gemm_run=gemm_run, dense_flavour=dense_flavour, branches=branches)
+    plan1 = nat.Plan(native, dims1, device, gemm_tile=planK.gemm_tile, gemm_run=gemm_run, dense_flavour=dense_flavour, branches=branches)
     flat, named, table = random_params(native, dims1, seed)
     clips = [synth_clip(10 + k, C, R, T, unp, density=density) for k in range(K)]
     params = flat.to(device)

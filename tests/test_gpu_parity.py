@@ -69,6 +69,15 @@ def test_large_linear_kernels_on_every_eligible_layer(native):
     pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 7, 3, 3, True, gemm_tile=64, dense_flavour=2)
 
 
+def test_branches_on_four_streams_match_the_oracle(native):
+    # mst_plan_options.branches = 1, eager launches: the passes really run on the caller's stream + three side streams with event
+    # waits where a dependency crosses streams — a missing dependency shows as a wrong gradient here (three shapes, repeated)
+    for rep in range(3):
+        pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 4, 16, 4, True, branches=1)
+    pc.oracle_case(native, torch.device('cuda:0'), pc.FULL, 7, 3, 3, True, branches=1)
+    pc.batch_case(native, torch.device('cuda:0'), pc.FULL, 3, 4, 2, True, 3, branches=1)
+
+
 def test_batched_32_bench_clips_configs3_per_gpu_share(native):
     # BASELINE.json configs[3]: minibatch 256 over 8 GPUs = 32 x (C=4, R=16, T=4) clips per GPU in one plan; against the
     # oracle clip by clip (outputs, 15 loss leaves per clip, summed gradient) and against 32 one-clip iterations bit for bit

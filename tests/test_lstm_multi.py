@@ -13,9 +13,9 @@ from style import _native as nat
 
 def lstm_steps(plan, backward=False):
     n = plan.lib.mst_plan_step_count(plan.handle, 7, int(backward))
-    info = np.zeros((n, 6), np.int32)
+    info = np.zeros((n, 8), np.int32)
     assert plan.lib.mst_plan_step_info(plan.handle, 7, int(backward), info.ctypes.data) == n
-    return [tuple(r) for r in info.tolist() if r[2] == 192]          # {B, S, H, multi, count, kind}
+    return [tuple(r) for r in info.tolist() if r[2] == 192]          # {B, S, H, multi, count, kind, level, chain}
 
 
 def run(plan, flat, clip, K=1):

@@ -35,7 +35,7 @@ def test_batched_plan_folds_the_clips_into_its_weight_gradient_gemms():
 def step_rows(plan, backward, mask=7):
     import numpy as np
     n = plan.lib.mst_plan_step_count(plan.handle, mask, int(backward))
-    info = np.zeros((n, 6), np.int32)
+    info = np.zeros((n, 8), np.int32)
     assert plan.lib.mst_plan_step_info(plan.handle, mask, int(backward), info.ctypes.data) == n
     return info.tolist()
 
@@ -51,7 +51,7 @@ def test_batched_plan_runs_its_large_linears_on_the_blocked_tiles():
     fwd = [r for r in step_rows(plan, False) if r[5] == 29]
     bwd = [r for r in step_rows(plan, True) if r[5] in (30, 31)]
     assert fwd and bwd
-    for rows, N, K, splits, count, kind in fwd + bwd:
+    for rows, N, K, splits, count, kind, level, chain in fwd + bwd:
         assert rows >= 512 and N > 32 and 2.0 * rows * N * K >= 4e6
     assert len([r for r in bwd if r[5] == 31]) == len(fwd)               # one weight-gradient launch per forward launch
     off = nat.Plan(native, dims, 'cpu', dense_flavour=1)
@@ -83,3 +83,19 @@ def test_single_launch_slab_reduce_guard_counts_columns_from_the_matrix_base():
     assert f(0, 40, 128 + 30, 20, 128) == 0      # blocks starting in different rows: still the same columns
     assert f(100, 40, 10, 20, 128) == 0          # a block that wraps a row is not a column block: never judged disjoint
     assert f(88, 40, 0, 88, 128) == 1
+
+
+def test_branches_spread_the_whole_model_lists_over_streams():
+    # mst_plan_options.branches = 1: every launch of the whole-model lists carries a stream (0 = the caller's, 1..3 = side
+    # streams) chosen along the dependency DAG; plan creation itself checks that every pair of launches that share memory
+    # is ordered by stream order and event waits (it falls back to one stream otherwise, which this test would see).
+    # Default plans keep one stream (chain -1 everywhere); per-stage lists are never spread.
+    native = sim_native()
+    dims = pc.make_dims(pc.FULL, 4, 16, 4, True)
+    spread = nat.Plan(native, dims, 'cpu', branches=1)
+    for backward in (False, True):
+        streams = [r[7] for r in step_rows(spread, backward)]
+        assert set(streams) <= {0, 1, 2, 3} and len(set(streams)) >= 2, streams
+        assert all(r[7] == -1 for r in step_rows(spread, backward, mask=1))
+    plain = nat.Plan(native, dims, 'cpu')
+    assert all(r[7] == -1 for r in step_rows(plain, False) + step_rows(plain, True))

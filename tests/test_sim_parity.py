@@ -69,6 +69,12 @@ def test_large_linear_kernels_at_small_sizes():
     pc.batch_case(sim_native(), 'cpu', pc.SMALL, 3, 3, 1, True, 3, gemm_tile=64, dense_flavour=2)
 
 
+def test_branches_keep_the_results():
+    # the stream assignment only changes where launches are queued; on the interpreter everything is sequential, so this pins the
+    # list order it produces (a valid order by construction) against the oracle and the bitwise golden comparison
+    pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True, branches=1)
+
+
 def test_single_clip_on_the_mfma_gemm(monkeypatch):
     monkeypatch.setenv('MST_GEMM', 'mfma')
     pc.oracle_case(sim_native(), 'cpu', pc.SMALL, 3, 2, 3, True, density=0.05, check_bitwise=True)

@@ -36,9 +36,9 @@ torch.cuda.synchronize()
 tot = 0
 for bwd in (False, True):
     steps = plan.time_steps(7, bwd, params, g, xp, xu, reps=20)
-    info = np.zeros(6 * len(steps), np.int32)
+    info = np.zeros(8 * len(steps), np.int32)
     native.lib.mst_plan_step_info(C.c_void_p(plan.handle), 7, int(bwd), C.c_void_p(info.ctypes.data))
-    info = info.reshape(-1, 6)
+    info = info.reshape(-1, 8)
     print('==== backward' if bwd else '==== forward')
     for i, ((kind, ms, fl, by), inf) in enumerate(zip(steps, info)):
         tot += ms
