@@ -524,6 +524,9 @@ def main():
     ap.add_argument('--tile-bars', action='store_true',
                     help='headline = BASELINE.json configs[4] instead: ONE long clip (C=8, R=151, T=4) with its bars tiled over the '
                          '--gpus ranks (strong scaling)')
+    ap.add_argument('--graphs', choices=['per-lane', 'joint'], default='joint',
+                    help="'streams' accumulation: one graph holding both lanes and the Adam step (default), or one hipGraph per lane "
+                         'replayed on its own stream + eager Adam (experiment, slower)')
     ap.add_argument('--accum', choices=['streams', 'batched'], default='streams',
                     help='B = 1: run the iter_size = 2 accumulation iterations on two streams (default) or as one 2-clip batched pass')
     args = ap.parse_args()
@@ -636,7 +639,22 @@ def main():
     with torch.cuda.stream(stream):
         pair(); optimizer_step()                                      # load code objects, size RCCL buffers
         stream.synchronize()
-        if not args.no_graph:
+        # --graphs per-lane (experiment): one hipGraph PER accumulation lane, each a single dependency chain replayed on its own
+        # stream, and the Adam launches behind a two-event join.  hipGraph on ROCm 7.2 replays a single chain with ~2 us per node
+        # boundary but a graph with parallel branches with ~5 us (tools/probe/capture_probe.cpp), so this was meant to keep the
+        # cheap boundary and the overlap; measured 1998 it/s against 2298 for the one joint graph (three replays, two joins and
+        # two launches per pair on the host side cost more than the boundaries save), so joint stays the default.
+        lane_graphs = None
+        if not args.no_graph and not batched and not os.environ.get('MST_BENCH_SEQ') and args.graphs == 'per-lane':
+            lane_graphs = []
+            for j in (0, 1):
+                side[j].wait_stream(stream)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side[j]):
+                    iteration(j)
+                lane_graphs.append(g)
+                stream.wait_stream(side[j])
+        elif not args.no_graph:
             graph_pair = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_pair, stream=stream):
                 pair()
@@ -644,7 +662,18 @@ def main():
                     optimizer_step()
 
         def two_steps():
-            if graph_pair is not None:
+            if lane_graphs is not None:
+                for j in (0, 1):
+                    side[j].wait_stream(stream)
+                    with torch.cuda.stream(side[j]):
+                        lane_graphs[j].replay()
+                for j in (0, 1):
+                    stream.wait_stream(side[j])
+                if dist is not None:
+                    grads[0].add_(grads[1])
+                    grads[1].zero_()
+                optimizer_step()
+            elif graph_pair is not None:
                 graph_pair.replay()
                 if dist is not None:
                     optimizer_step()
@@ -701,15 +730,22 @@ def main():
         # train-model.py:102-103): pinned host copies of the note tensors go to the device on a copy stream, double-buffered so
         # that the upload of pair i + 1 overlaps the compute of pair i; one graph per input buffer
         with_upload = None
-        if rank == 0 and world == 1 and not batched and graph_pair is not None:
+        if rank == 0 and world == 1 and not batched and (graph_pair is not None or lane_graphs is not None):
             hxp, hxu = xp.cpu().pin_memory(), xu.cpu().pin_memory()
             bufs = [(xp, xu), (torch.empty_like(xp), torch.empty_like(xu))]
-            graphs = [graph_pair, torch.cuda.CUDAGraph()]
+            graphs = [graph_pair, torch.cuda.CUDAGraph()]             # (this leg replays one joint graph per input buffer)
             xp_main, xu_main = xp, xu
-            xp, xu = bufs[1]
-            with torch.cuda.graph(graphs[1], stream=stream):
-                pair()
-                optimizer_step()
+            for j in (0, 1):
+                if graphs[j] is not None:
+                    continue
+                graphs[j] = torch.cuda.CUDAGraph()
+            for j in (0, 1):
+                if graphs[j] is graph_pair:
+                    continue
+                xp, xu = bufs[j]
+                with torch.cuda.graph(graphs[j], stream=stream):
+                    pair()
+                    optimizer_step()
             xp, xu = xp_main, xu_main
             copy = torch.cuda.Stream(dev)
             up_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -757,7 +793,9 @@ def main():
                                      'one 30 s clip per GPU (BASELINE.json configs[1])') +
                                     ': piano-roll C=4,R=16,T=4 (+percussion), full widths (980325 params), fwd+loss+bwd every '
                                     'step, Adam+StepLR every iter_size steps',
-                           clips_per_gpu=B, iter_size=iter_size, hip_graph=graph_pair is not None,
+                           clips_per_gpu=B, iter_size=iter_size, hip_graph=graph_pair is not None or lane_graphs is not None,
+                           graphs=('one per accumulation lane (single chains) + Adam launches' if lane_graphs is not None else
+                                   ('one joint graph' if graph_pair is not None else 'none')),
                            accumulation=('batched plan, %d clips per launch' % K) if batched else '2 concurrent streams',
                            launches_per_pass=plan.launch_count(7, False) + plan.launch_count(7, True) + 3,      # + 3 loss kernels
                            parallelism=f'dp{world} ({"RCCL" if args.backend == "nccl" else args.backend} all-reduce SUM of {n} fp32 grads per optimizer step)' if world > 1 else 'single GPU',
