@@ -832,16 +832,14 @@ int launch_gather(const GatherDesc* dev, int count, int max_rows, Bases b, hipSt
 // odometer over the reduced dims (no divisions in the loop), eight loads in flight, and adds them in row
 // order.  No LDS, no barriers, and a workgroup always has 256 outputs' worth of work (a workgroup per
 // destination row left most lanes idle: the broadcast segments are 5-48 columns wide).
-__global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, int members, int blocks_per_clip, Bases b) {
-    // flat grid, clip-major: inside a clip's block range member y owns [blk_begin, blk_begin + ceil(nidx*nchunk*width / 256))
-    const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
-    int y = 0;
-    while (y + 1 < members && lb >= descs[y + 1].blk_begin) ++y;
-    const SegRedDesc d = descs[clip * members + y];
-    const int e = (lb - d.blk_begin) * 256 + threadIdx.x;
-    if (e >= d.nidx * d.nchunk * d.width) return;
-    const int w = e % d.width;
-    int t = e / d.width;
+// E consecutive columns per lane (the index arithmetic — a dozen integer divisions — is then paid once per E outputs), R reduced
+// rows in flight per round trip.  Every output is still its rows added in row order.
+template <int E, int R>
+__device__ __forceinline__ void segred_body(const SegRedDesc& d, const int item, const Bases& b) {
+    const int wgrp = (d.width + E - 1) / E;
+    if (item >= d.nidx * d.nchunk * wgrp) return;
+    const int w = (item % wgrp) * E, ne = min(E, d.width - w);
+    int t = item / wgrp;
     const int chunk = t % d.nchunk, idx = t / d.nchunk;
     int kc[4];
     t = idx;
@@ -862,33 +860,77 @@ __global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restric
     auto advance = [&]() {
         if (++cr[3] == rd[3]) { cr[3] = 0; if (++cr[2] == rd[2]) { cr[2] = 0; if (++cr[1] == rd[1]) { cr[1] = 0; ++cr[0]; } } }
     };
-    float acc = 0.f;
+    float acc[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[j] = 0.f;
+    // a full group of four is ONE 16-byte load (rows are only 4-byte aligned: the 4-byte-aligned vector type); the ragged last group
+    // of a row loads its live columns one by one
+    typedef float sr_f4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto ldE = [&](const float* p, float (&dst)[E]) {
+        if (E == 4 && ne == 4) {
+            const sr_f4 t = *reinterpret_cast<const sr_f4*>(p);
+#pragma unroll
+            for (int j = 0; j < E; ++j) dst[j] = t[j < 4 ? j : 0];
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) dst[j] = p[j < ne ? j : 0];
+        }
+    };
     int rr = r_begin;
-    for (; rr + 8 <= r_end; rr += 8) {                 // 8 loads in flight per round trip, added in row order
-        int64_t o[8];
+    for (; rr + R <= r_end; rr += R) {                 // R x E loads in flight per round trip, added in row order
+        int64_t o[R];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { o[q] = offset(); advance(); }
-        float v[8];
+        for (int q = 0; q < R; ++q) { o[q] = offset(); advance(); }
+        float v[R][E];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = src[o[q]];
+        for (int q = 0; q < R; ++q) ldE(src + o[q], v[q]);
         if (d.act != ACT_NONE) {
-            float y[8];
+            float y[R][E];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) y[q] = ysrc[o[q]];
+            for (int q = 0; q < R; ++q) ldE(ysrc + o[q], y[q]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] *= act_bwd(d.act, y[q], d.start + w);
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[q][j] *= act_bwd(d.act, y[q][j], d.start + w + j);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += v[q];
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) acc[j] += v[q][j];
     }
     for (; rr < r_end; ++rr) {
         const int64_t o = offset();
-        float v = src[o];
-        if (d.act != ACT_NONE) v *= act_bwd(d.act, ysrc[o], d.start + w);
-        acc += v; advance();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int jj = j < ne ? j : 0;
+            float v = src[o + jj];
+            if (d.act != ACT_NONE) v *= act_bwd(d.act, ysrc[o + jj], d.start + w + j);
+            acc[j] += v;
+        }
+        advance();
     }
-    if (d.nchunk == 1) { float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld + w; *dst = d.first ? acc : *dst + acc; }
-    else b.p[SP_TMP][d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width + w] = acc;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (j >= ne) break;
+        if (d.nchunk == 1) { float* dst = b.p[SP_GRAD] + d.dst_off + (int64_t)idx * d.dst_ld + w + j; *dst = d.first ? acc[j] : *dst + acc[j]; }
+        else b.p[SP_TMP][d.part_off + ((int64_t)idx * d.nchunk + chunk) * d.width + w + j] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void segred_kernel(const SegRedDesc* __restrict__ descs, int members, int blocks_per_clip, Bases b) {
+    // flat grid, clip-major: inside a clip's block range member y owns [blk_begin, blk_begin + ceil(nidx*nchunk*width / 256))
+    // (sized for one column per lane; a wide member uses the first quarter of its workgroups, the others retire at once)
+    const int clip = blockIdx.x / blocks_per_clip, lb = blockIdx.x - clip * blocks_per_clip;
+    int y = 0;
+    while (y + 1 < members && lb >= descs[y + 1].blk_begin) ++y;
+    const SegRedDesc d = descs[clip * members + y];
+    const int e = (lb - d.blk_begin) * 256 + threadIdx.x;
+    // four columns per lane only where nothing is reduced (a strided copy: index arithmetic per element was all its time, 68.7 ->
+    // 40.6 us for the 456-wide one at 64 clips); a member that sums rows is latency bound and wants every lane it can get
+    // (four columns per lane there: 33.6 -> 77.5 us)
+    const bool copy = (d.kd[0] == 1 ? d.d[0] : 1) * (d.kd[1] == 1 ? d.d[1] : 1) * (d.kd[2] == 1 ? d.d[2] : 1) * (d.kd[3] == 1 ? d.d[3] : 1) == 1;
+    if (copy && d.width >= 64) segred_body<4, 1>(d, e, b);
+    else segred_body<1, 8>(d, e, b);
 }
 
 __global__ __launch_bounds__(256) void segred2_kernel(const SegRedDesc* __restrict__ descs, Bases b) {
