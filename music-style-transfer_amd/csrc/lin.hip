@@ -294,6 +294,170 @@ __global__ __launch_bounds__(256, 2) void lin_dw_kernel(const LinDesc d, Bases b
     }
 }
 
+// ---- N <= 16 outputs (the rhythm encoder's 280 -> 16 Linear over every (position, fraction) row of the raw note tensor: 183 MB of
+// input per 64-clip launch and 1.5 GFLOP — an HBM stream, not a GEMM).  A 64-column tile would idle 3/4 of its MFMA columns and
+// a 2 x 2-blocked wave has nothing to reuse, so these two kernels use v_mfma_f32_16x16x4_f32 (the 16 outputs ARE the tile width),
+// read every input row exactly once per pass (forward: 256-row tiles; weight gradient: ONE tile spans all K + 1 <= 320 columns,
+// so a k-split reads its rows once) and keep 2-3 workgroups x 32-40 KB of loads in flight per CU.
+typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
+#define LN16_JMAX 320
+
+__global__ __launch_bounds__(256, 2) void lin16_fwd_kernel(const LinDesc d, Bases b) {
+    constexpr int BM = 256, PA = BM + 1, QA = BM / 32;
+    __shared__ float As[LN_KT][PA];
+    __shared__ float Bs[LN_KT][17];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wv = MST_UNIFORM(tid >> 6);
+    const int64_t Mtot = (int64_t)d.clips * d.rows;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const ln_gp xa = (ln_gp)(b.p[d.x_space] + d.x_off);
+    const ln_gp w = (ln_gp)(b.p[SP_PAR] + d.w_off);
+    unsigned aoff[QA];
+    bool aon[QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int64_t m = m0 + (tid >> 3) + 32 * q;
+        aon[q] = m < Mtot;
+        const unsigned mm = aon[q] ? (unsigned)m : 0u;
+        const unsigned clip = mm / (unsigned)d.rows, r = mm - clip * (unsigned)d.rows;
+        aoff[q] = (unsigned)((int64_t)clip * d.x_cs + (int64_t)r * d.x_ld);
+    }
+    const int bn = tid >> 3;                                   // lanes 0..127: weight row n = bn, k group tid & 7
+    const bool bon = tid < 128 && bn < d.N;
+    ln_f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = ln_f32x4{0.f, 0.f, 0.f, 0.f};
+    ln_f4 ra[QA], rb;
+    auto issue = [&](const int kt) {
+        const int ka = kt + 4 * (tid & 7);
+#pragma unroll
+        for (int q = 0; q < QA; ++q) ra[q] = ln_ld4(xa + aoff[q], ka, d.K, aon[q]);
+        rb = ln_ld4(w + (unsigned)((bon ? bn : 0) * d.K), ka, d.K, bon);
+    };
+    issue(0);
+    for (int kt = 0; kt < d.K; kt += LN_KT) {
+        const int ka = kt + 4 * (tid & 7);
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            const ln_f4 v = ln_fix4(ra[q], ka, d.K, aon[q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[4 * (tid & 7) + j][(tid >> 3) + 32 * q] = v[j];
+        }
+        if (tid < 128) {
+            const ln_f4 v = ln_fix4(rb, ka, d.K, bon);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[4 * (tid & 7) + j][bn] = v[j];
+        }
+        MST_LDS_BARRIER();
+        if (kt + LN_KT < d.K) issue(kt + LN_KT);
+#pragma unroll
+        for (int ks = 0; ks < LN_KT / 4; ++ks) {
+            const int k = 4 * ks + kq;
+            const float bv = Bs[k][l15];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[k][wv * 64 + 16 * q + l15], bv, acc[q], 0, 0, 0);
+        }
+        MST_LDS_BARRIER();
+    }
+    // epilogue: lane -> column l15, rows 16 q + 4 kq + j of the wave's 64: one division, then (clip, row) advance by the row deltas
+    if (l15 >= d.N) return;
+    const float bias = b.p[SP_PAR][d.b_off + l15];
+    float* out = b.p[SP_WS] + d.y_off;
+    const unsigned mb = (unsigned)m0 + (unsigned)(wv * 64 + 4 * kq);
+    unsigned eclip = mb / (unsigned)d.rows, erow = mb - eclip * (unsigned)d.rows, eprev = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned delta = 16 * q + j;
+            erow += delta - eprev; eprev = delta;
+            { const bool wr = erow >= (unsigned)d.rows; erow -= wr ? (unsigned)d.rows : 0u; eclip += wr ? 1u : 0u; }      // rows >= 32: one wrap at most
+            if ((int64_t)mb + delta >= Mtot) continue;
+            out[(int64_t)eclip * d.y_cs + (int64_t)erow * d.y_ld + l15] = ln_act_fwd(d.act, acc[q][j] + bias, l15);
+        }
+}
+
+// dW | db for N <= 16: A(n, k = m) = dYa[m][n], B(k = m, j) = [X | 1][m][j]; the tile is N x (K + 1 <= 320): wave w owns column blocks
+// 5 w .. 5 w + 4 (16 columns each).  Row m of a k-tile belongs to the eight lanes tid / 8 = m: one (clip, row) pair per lane.
+__global__ __launch_bounds__(256, 2) void lin16_dw_kernel(const LinDesc d, Bases b) {
+    constexpr int PB = LN16_JMAX + 16;
+    __shared__ float As[LN_KT][17];
+    __shared__ __attribute__((aligned(16))) float Bs[LN_KT][PB];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wv = MST_UNIFORM(tid >> 6);
+    const int split = blockIdx.x;
+    const int64_t Mtot = (int64_t)d.clips * d.rows;
+    const int64_t k0 = (int64_t)split * d.rows_per_split, k1 = min(Mtot, k0 + d.rows_per_split);
+    const ln_gp gy = (ln_gp)(b.p[SP_GRAD] + d.y_off), yy = (ln_gp)(b.p[SP_WS] + d.y_off), xx = (ln_gp)(b.p[d.x_space] + d.x_off);
+    const int mrow = tid >> 3, t7 = tid & 7;                   // row of the k-tile, column-group phase
+    const int an = 4 * (t7 & 3);                               // lanes with t7 < 4 also carry the row's four groups of dY / Y
+    const int act = d.act;
+    ln_f32x4 acc[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = ln_f32x4{0.f, 0.f, 0.f, 0.f};
+    ln_f4 ra, ry, rb[10];
+    unsigned rc, rr;                                           // (clip, row inside the clip) of this lane's row of the next k-tile
+    {
+        const unsigned f = (unsigned)k0 + (unsigned)mrow;
+        rc = f / (unsigned)d.rows; rr = f - rc * (unsigned)d.rows;
+    }
+    auto issue = [&](const int64_t kt) {
+        const bool on = kt + mrow < k1;
+        const unsigned clip = on ? rc : 0u, r = on ? rr : 0u;
+        const unsigned oy = (unsigned)((int64_t)clip * d.y_cs + (int64_t)r * d.y_ld);
+        const unsigned ox = (unsigned)((int64_t)clip * d.x_cs + (int64_t)r * d.x_ld);
+        if (t7 < 4) { ra = ln_ld4(gy + oy, an, d.N, on); ry = ln_ld4(yy + oy, an, d.N, on); }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) rb[q] = ln_ld4(xx + ox, 4 * (t7 + 8 * q), d.K, on);
+        rr += LN_KT; if (rr >= (unsigned)d.rows) { rr -= (unsigned)d.rows; ++rc; }
+    };
+    if (k0 < k1) issue(k0);
+    for (int64_t kt = k0; kt < k1; kt += LN_KT) {
+        const bool on = kt + mrow < k1;
+        if (t7 < 4) {
+            ln_f4 v = ln_fix4(ra, an, d.N, on);
+            const ln_f4 y = ln_fix4(ry, an, d.N, on);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[mrow][an + j] = v[j] * ln_act_bwd(act, y[j], an + j);
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const int bj = 4 * (t7 + 8 * q);
+            ln_f4 v = ln_fix4(rb[q], bj, d.K, on);
+            if (on && bj <= d.K && bj + 3 >= d.K) {            // the bias-gradient column: [X | 1]
+                const int c1 = d.K - bj;
+                v[0] = c1 == 0 ? 1.f : v[0]; v[1] = c1 == 1 ? 1.f : v[1]; v[2] = c1 == 2 ? 1.f : v[2]; v[3] = c1 == 3 ? 1.f : v[3];
+            }
+            float* dst = &Bs[mrow][bj];
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        MST_LDS_BARRIER();
+        if (kt + LN_KT < k1) issue(kt + LN_KT);
+#pragma unroll
+        for (int ks = 0; ks < LN_KT / 4; ++ks) {
+            const int k = 4 * ks + kq;
+            const float av = As[k][l15];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[k][(wv * 5 + q) * 16 + l15], acc[q], 0, 0, 0);
+        }
+        MST_LDS_BARRIER();
+    }
+    // this split's slab, parameter layout: weight (N x K) then bias (N); lane -> column j, outputs n = 4 kq + i
+    float* slab = b.p[SP_TMP] + d.slab_off + (int64_t)split * d.slab_stride;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int j = (wv * 5 + q) * 16 + l15;
+        if (j > d.K) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 4 * kq + i;
+            if (n >= d.N) continue;
+            if (j < d.K) slab[(int64_t)n * d.K + j] = acc[q][i];
+            else slab[(int64_t)d.N * d.K + n] = acc[q][i];
+        }
+    }
+}
+
 // tile shape by the output's column count: <= 64 columns -> four waves stacked over the rows (256 x 64), else 2 x 2 (128 x 128)
 int lin_rows_blocks(const LinDesc& d, int mode) {
     const int nc = mode == 0 ? d.N : d.K;
@@ -301,7 +465,12 @@ int lin_rows_blocks(const LinDesc& d, int mode) {
     if (nc <= 64) return (int)((mtot + 255) / 256);
     return (int)((mtot + 127) / 128) * ((nc + 127) / 128);
 }
+static bool lin_is16(const LinDesc& d) { return d.N <= 16 && d.K + 1 <= LN16_JMAX; }
 int launch_lin_fwd(const LinDesc& d, Bases b, hipStream_t s) {
+    if (lin_is16(d)) {
+        hipLaunchKernelGGL(lin16_fwd_kernel, dim3((unsigned)(((int64_t)d.clips * d.rows + 255) / 256)), dim3(256), 0, s, d, b);
+        return (int)hipGetLastError();
+    }
     const dim3 grid(lin_rows_blocks(d, 0));
     if (d.N <= 64) hipLaunchKernelGGL((lin_rows_kernel<4, 1, 0>), grid, dim3(256), 0, s, d, b, 0);
     else hipLaunchKernelGGL((lin_rows_kernel<2, 2, 0>), grid, dim3(256), 0, s, d, b, 0);
@@ -315,10 +484,15 @@ int launch_lin_dx(const LinDesc& d, Bases b, int first, hipStream_t s) {
 }
 // weight-gradient tile: <= 64 outputs -> 64 x 256 (four waves side by side), else 128 x 128
 int lin_dw_tiles(const LinDesc& d) {
+    if (lin_is16(d)) return 1;
     if (d.N <= 64) return (d.K + 1 + 255) / 256;
     return ((d.N + 127) / 128) * ((d.K + 1 + 127) / 128);
 }
 int launch_lin_dw(const LinDesc& d, Bases b, hipStream_t s) {
+    if (lin_is16(d)) {
+        hipLaunchKernelGGL(lin16_dw_kernel, dim3(d.splits), dim3(256), 0, s, d, b);
+        return (int)hipGetLastError();
+    }
     const dim3 grid(lin_dw_tiles(d) * d.splits);
     if (d.N <= 64) hipLaunchKernelGGL((lin_dw_kernel<1, 4>), grid, dim3(256), 0, s, d, b);
     else hipLaunchKernelGGL((lin_dw_kernel<2, 2>), grid, dim3(256), 0, s, d, b);

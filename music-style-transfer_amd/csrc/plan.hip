@@ -470,11 +470,12 @@ struct mst_plan {
         Op op; op.stage = stage;
         // Plans on the throughput tiling run their large dense Linears on lin.hip's kernels (2 x 2-blocked MFMA tiles, all clips
         // as rows of one launch): row-major input in the workspace or a borrowed note tensor, >= 512 rows and >= 4 MFLOP per clip
-        // and more than one 32-column MFMA block of outputs.  The rule does not look at the clip count: a one-clip plan forced
+        // and more than one 32-column MFMA block of outputs — or at most 16 outputs of a long input row (the 16x16x4 stream kernels).  The rule does not look at the clip count: a one-clip plan forced
         // onto this tiling takes the same kernels, so "batched == one clip at a time, bit for bit" holds by construction.
         if (mfma_plan() && opt.dense_flavour != 1 && !pb && rows >= 32 && K >= 4 && N >= 4 && (space == SP_WS || ((space == SP_EXT0 || space == SP_EXT1) && !xgrad)) &&
             boff == woff + (int64_t)N * K && (int64_t)this->K() * rows < ((int64_t)1 << 30) &&
-            (opt.dense_flavour == 2 || (rows >= 512 && N > 32 && 2.0 * rows * N * K >= 4e6))) {
+            (opt.dense_flavour == 2 || (rows >= 512 && N > 32 && 2.0 * rows * N * K >= 4e6) ||
+             (rows >= 512 && N <= 16 && K >= 128 && K + 1 <= 320 && !xgrad))) {       // the N <= 16 stream kernels: 280 -> 16 over every note row
             LinDesc l{}; l.rows = rows; l.K = K; l.N = N; l.act = act; l.xgrad = xgrad ? 1 : 0; l.clips = this->K();
             l.x_space = space; l.x_ld = xld; l.x_off = xoff; l.y_ld = out.ld; l.y_off = out.off; l.w_off = woff; l.b_off = boff;
             const int64_t mtot = (int64_t)this->K() * rows;
