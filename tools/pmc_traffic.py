@@ -34,15 +34,16 @@ def is_setup(name):
 
 
 def per_iteration(fetch, write, clips):
-    # passes = launches of loss_tail_kernel (one per pass, nothing else launches it)
-    iters = float(clips) * fetch['loss_tail_kernel']['launches']
+    # passes = launches of loss_tail_kernel (one per pass, nothing else launches it), counted PER RUN: the two counter runs
+    # repeat their timed region until 0.25 s have passed and need not make the same number of passes
+    it_f, it_w = float(clips) * fetch['loss_tail_kernel']['launches'], float(clips) * write['loss_tail_kernel']['launches']
     def total(tab, setup):
         return sum(v['launches'] * v['avg_kb_per_launch'] for k, v in tab.items() if is_setup(k) == setup) * 1024
-    f, w = total(fetch, False) / iters, total(write, False) / iters
-    return dict(iterations=iters, fetch_bytes=f, write_bytes=w, hbm_bytes=f + w,
+    f, w = total(fetch, False) / it_f, total(write, False) / it_w
+    return dict(iterations_fetch_run=it_f, iterations_write_run=it_w, fetch_bytes=f, write_bytes=w, hbm_bytes=f + w,
                 setup_bytes_whole_run=total(fetch, True) + total(write, True),
-                note='all kernels of the timed loop (model, loss, optimizer) / iterations; raw counters; setup_bytes_whole_run = '
-                     'one-time fills / uploads before the loop (torch fill kernels, runtime copies), not included')
+                note='all kernels of the timed loop (model, loss, optimizer) / iterations of the same run; raw counters; '
+                     'setup_bytes_whole_run = one-time fills / uploads before the loop (torch fill kernels, runtime copies), not included')
 
 
 if len(sys.argv) > 5:
