@@ -86,11 +86,18 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_fwd_kernel(const LstmDe
         MST_LDS_BARRIER();
         if (REG) {
             if (tid < G) {
+                // all of h_{t-1} into registers first (sixteen 16-byte broadcast reads, ONE wait), then the FMAs: left to itself the
+                // compiler feeds the chains two reads at a time with a wait in front of every second FMA — eight LDS round trips per
+                // step on the sequential path.  (One wave per SIMD: registers are not what this kernel is short of.)
+                float hv[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) hv[k] = h_s[k];
+                __builtin_amdgcn_sched_barrier(0);
                 float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;       // 4 independent FMA chains
 #pragma unroll
                 for (int k = 0; k < 64; k += 4) {
-                    z0 = fmaf(w[k], h_s[k], z0); z1 = fmaf(w[k + 1], h_s[k + 1], z1);
-                    z2 = fmaf(w[k + 2], h_s[k + 2], z2); z3 = fmaf(w[k + 3], h_s[k + 3], z3);
+                    z0 = fmaf(w[k], hv[k], z0); z1 = fmaf(w[k + 1], hv[k + 1], z1);
+                    z2 = fmaf(w[k + 2], hv[k + 2], z2); z3 = fmaf(w[k + 3], hv[k + 3], z3);
                 }
                 z_s[tid] = (z0 + z1) + (z2 + z3);
             }
@@ -247,12 +254,16 @@ __global__ __launch_bounds__(REG ? 256 : 1024) void lstm_bwd_kernel(const LstmDe
             if (REG) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const int base = part * H;
+                float dv[64];                                 // the gate's dz slice in registers first, then the FMAs (see lstm_fwd_kernel)
+#pragma unroll
+                for (int jj = 0; jj < 64; ++jj) dv[jj] = dz_s[min(base + jj, G - 1)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < 64; jj += 4) {
-                    a0 = fmaf(w[jj], dz_s[min(base + jj, G - 1)], a0);
-                    a1 = fmaf(w[jj + 1], dz_s[min(base + jj + 1, G - 1)], a1);
-                    a2 = fmaf(w[jj + 2], dz_s[min(base + jj + 2, G - 1)], a2);
-                    a3 = fmaf(w[jj + 3], dz_s[min(base + jj + 3, G - 1)], a3);
+                    a0 = fmaf(w[jj], dv[jj], a0);
+                    a1 = fmaf(w[jj + 1], dv[jj + 1], a1);
+                    a2 = fmaf(w[jj + 2], dv[jj + 2], a2);
+                    a3 = fmaf(w[jj + 3], dv[jj + 3], a3);
                 }
                 acc = (a0 + a1) + (a2 + a3);
             } else {
