@@ -1,5 +1,7 @@
+# One gpurun call that checks a tree end to end on an MI355X: GPU test suite, smoke(), the default bench line.
+# Usage: gpurun --timeout 1200 -- bash tools/verify_gpu.sh <tag>   (writes gpurun_out/<tag>_*)
 set -o pipefail
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=${1:-r3fin}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; T=${1:-verify}
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${T}_tests.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout -k 10 600 python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err; echo "bench rc=$?"
