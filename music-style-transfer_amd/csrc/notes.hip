@@ -395,12 +395,16 @@ template <int ML, int MEL>
 __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __restrict__ dp, Bases b) {
     const NotesDesc d = dp[blockIdx.y];
     constexpr int KL = PSA_HW + ML;
-    __shared__ float w_s[NPF * KL], b_s[NPF];
+    // the output Linear's weights TRANSPOSED, [input][output padded to 8]: the five outputs of one input sit side by side, so the
+    // packed FMAs take (w[j][i], w[j][i + 1]) straight from one 16-byte broadcast read (row-major, the compiler spent 1.5 v_mov per
+    // v_pk_fma_f32 on pairing elements of two weight rows)
+    __shared__ __attribute__((aligned(16))) float w_s[KL][8];
+    __shared__ float b_s[NPF];
     __shared__ float wm_s[ML * MEL], bm_s[ML];
     __shared__ float lo_s[NOCT * PSA_HW], ld_s[NDEG * PSA_HW];
     const int tid = threadIdx.x;
     const float* par = b.p[SP_PAR];
-    for (int i = tid; i < NPF * KL; i += 64) w_s[i] = par[d.wl_off + i];
+    for (int i = tid; i < NPF * KL; i += 64) w_s[i % KL][i / KL] = par[d.wl_off + i];
     for (int i = tid; i < ML * MEL; i += 64) wm_s[i] = par[d.wm_off + i];
     if (tid < ML) bm_s[tid] = par[d.wm_off + ML * MEL + tid];
     if (tid < NPF) b_s[tid] = par[d.bl_off + tid];
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
                 for (int q = 0; q < MEL; ++q) a = fmaf(wm_s[k * MEL + q], mel[q], a);
                 const float mlk = lrelu(a);
 #pragma unroll
-                for (int i = 0; i < NPF; ++i) zm[i] = fmaf(w_s[i * KL + PSA_HW + k], mlk, zm[i]);
+                for (int i = 0; i < NPF; ++i) zm[i] = fmaf(w_s[PSA_HW + k][i], mlk, zm[i]);
             }
         }
         for (int c = 0; c < d.C; ++c) {
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(64) void psa_notes_fwd_kernel(const NotesDesc* __re
                 for (int j = 0; j < PSA_HW; ++j) {
                     const float h = lrelu(lo_s[o * PSA_HW + j] + ld_s[dg * PSA_HW + j]);
 #pragma unroll
-                    for (int i = 0; i < NPF; ++i) z[i] = fmaf(w_s[i * KL + j], h, z[i]);
+                    for (int i = 0; i < NPF; ++i) z[i] = fmaf(w_s[j][i], h, z[i]);
                 }
                 float* out = ws + d.out_off + (row * NPN + n) * NPF;
 #pragma unroll
