@@ -625,7 +625,9 @@ __device__ __forceinline__ void gemm_fast_body(const GemmDesc& d, const Bases& b
         // run full 32x32 MFMAs on all four waves, two or three of them on padding.  The waves a tile does not need for
         // blocks take a slice of the k-tile instead: nblk = live 32x32 blocks, wave w -> block w % nblk, k-slice w / nblk;
         // the slices' accumulators meet in LDS at the tile's last k-tile, summed in slice order.
-        const int mb = (M - tm * MF_BM > 32) ? 2 : 1, nb = (N - tn * MF_BN > 32) ? 2 : 1, nblk = mb * nb;
+        // (clips-as-rows GEMMs never slice: their row count is the clip count, and a clip's results must not depend on how many
+        // clips share the launch — every output stays one k-ascending chain whatever M is)
+        const int mb = (d.clip_rows || M - tm * MF_BM > 32) ? 2 : 1, nb = (d.clip_rows || N - tn * MF_BN > 32) ? 2 : 1, nblk = mb * nb;
         const int blk = wv % nblk, ks = wv / nblk, nsl = 4 / nblk;
         const int bm = blk / nb, bn = blk - bm * nb;
         {

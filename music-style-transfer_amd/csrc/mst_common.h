@@ -121,6 +121,9 @@ struct GemmDesc {
     // One GEMM instead of one per clip: no k-tile padding at short sequences, clips x fewer slab rows to reduce.
     int32_t fold_rows;   // 0 = not folded
     int64_t acs, acs2, bcs;
+    // Linears over ONE row per clip (style / song-info heads) of a batched plan: the clips are the rows of one GEMM — M = clips,
+    // row stride = the clip's arena stride (set at schedule time) — so the weights are read once instead of once per clip.
+    int32_t clip_rows;   // 1 = built for one clip with M = 1; scheduled with M = clips
     Operand A, B;
     OutSpec out;
 };

@@ -505,7 +505,11 @@ struct mst_plan {
             else { g.B.kind = OPK_DENSE; g.B.space = SP_PAR; g.B.off = woff; g.B.si = 1; g.B.sj = K; g.B.ones_at = -1; g.B.kfast = 1; }
             g.out.kind = OUT_STORE; g.out.space = SP_WS; g.out.ldc = out.ld; g.out.act = act; g.out.off = out.off;
             g.out.bias_space = SP_PAR; g.out.bias_off = boff;
-            op.fwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
+            // one row per clip (the style / song-info heads): batched plans on the 64x64 tiling run the clips as the rows of ONE
+            // GEMM (GemmDesc.clip_rows) — like the folded weight gradients, one descriptor for all clips
+            // (a one-clip plan on this tiling marks them too: the flag also pins the summation order, gemm.hip)
+            g.clip_rows = (mfma_plan() && rows == 1 && !pb && space == SP_WS) ? 1 : 0;
+            op.fwd.push_back(Step{(g.clip_rows && folds_clips()) ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(rows, N), 1});
             gemms.push_back(g);
         }
         {   // dW | db  =  (dY o act')^T [X | 1]
@@ -533,7 +537,8 @@ struct mst_plan {
             a.A.ld = out.ld; a.A.act = act; a.A.transposed = 0; a.A.kfast = 1;
             a.B.kind = OPK_DENSE; a.B.space = SP_PAR; a.B.off = woff; a.B.si = K; a.B.sj = 1; a.B.ones_at = -1; a.B.kfast = 0;
             a.out.kind = OUT_ACCUM; a.out.space = SP_GRAD; a.out.off = xoff; a.out.ldc = xld; a.out.bias_space = -1; a.out.act = ACT_NONE;
-            op.bwd.push_back(Step{K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
+            a.clip_rows = (mfma_plan() && rows == 1 && !pb && space == SP_WS) ? 1 : 0;
+            op.bwd.push_back(Step{(a.clip_rows && folds_clips()) ? K_GEMM_FOLD : K_GEMM, (int)gemms.size(), 1, tiles(rows, K), 1});
             gemms.push_back(a);
         }
         ops.push_back(op);
@@ -1224,13 +1229,16 @@ void mst_plan::accesses(const Step& s, std::vector<Acc>& v, bool scheduled) cons
         case K_GEMM: case K_GEMM_FOLD: {
             const GemmDesc& g = gemms[s.first + i];
             const int gk = g.fold_rows ? g.fold_rows : g.K;      // a folded reduction touches, per clip, what one clip's would
-            operand_acc(v, g.A, g.M, gk, -1);
+            const int gm = g.clip_rows ? 1 : g.M;                // ... and so do clips-as-rows (its scheduled copy has M = clips)
+            Operand ga = g.A;
+            if (g.clip_rows && ga.kind == OPK_ACTGRAD) ga.ld = gk;       // one row of gk columns (its scheduled pitch is the clip stride)
+            operand_acc(v, ga, gm, gk, -1);
             operand_acc(v, g.B, gk, g.N, g.B.ones_at);
             const OutSpec& o = g.out;
             if (o.bias_space >= 0)       // a bias row that is an activation (linear_part); bias_div: one row per bias_div output rows
                 acc_add(v, o.bias_space, o.bias_off, o.bias_div > 0 ? (int64_t)((g.M - 1) / o.bias_div) * o.bias_ld + g.N : g.N, false);
-            if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true);
-            else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(g.M - 1) * o.ldc + g.N, true, true, g.N == o.ldc || g.M == 1);
+            if (o.kind == OUT_STORE) acc_add(v, o.space, o.off, (int64_t)(gm - 1) * o.ldc + g.N, true);
+            else if (o.kind == OUT_ACCUM) acc_add(v, o.space, o.off, (int64_t)(gm - 1) * o.ldc + g.N, true, true, g.N == o.ldc || gm == 1);
             else if (o.kind == OUT_CONV) acc_add(v, o.space, o.off, (int64_t)(g.M / NOCT) * o.ldc, true);
             else acc_add(v, o.space, o.off, o.slab_stride * g.ksplit, true);
             break;
@@ -1499,6 +1507,13 @@ void mst_plan::schedule_pass(const std::vector<Step>& seq, std::vector<Step>& ou
                             // the loader adds clip * stride as a 32-bit element offset
                             if ((uint64_t)std::max(g.acs, std::max(g.acs2, g.bcs)) * (uint64_t)K() > 0xFFFFFFFFull) err = MST_ERR_UNSUPPORTED;
                         }
+                        if (g.clip_rows) {          // the clips become the rows: row stride = the clip stride of the operand's arena
+                            g.M = K();
+                            if (g.A.kind == OPK_DENSE) g.A.si = shift(g.A.space, 1);
+                            else g.A.ld = (int32_t)shift(g.A.space, 1);              // OPK_ACTGRAD: dY and Y share the stride
+                            g.out.ldc = (int32_t)shift(g.out.space, 1);
+                            if ((uint64_t)act_top * (uint64_t)K() > 0x7FFFFFFFull) err = MST_ERR_UNSUPPORTED;     // 32-bit row offsets
+                        }
                         const int kr = (g.K + g.ksplit - 1) / g.ksplit;
                         g.kdsel = kr <= 32 ? 0 : (kr <= 64 ? 1 : 2);
                         // tiles per workgroup (64x64 tiling): measured on MI355X at 64 clips per launch, runs of 2 / 4 / 8 tiles
@@ -1603,6 +1618,7 @@ void mst_plan::first_writers(std::vector<Step>& list, size_t begin, bool per_sta
             for (int k = 0; k < copies && !plain; ++k) {
                 const int idx = m.first + k * nm + q;
                 if (m.kind == K_GEMM) s_gemms[idx].out.first = first;
+                else if (m.kind == K_GEMM_FOLD) { if (k == 0) s_gemms[m.first + q].out.first = first; }      // one descriptor for all clips (clips-as-rows dX)
                 else if (m.kind == K_SEGRED) s_segreds[idx].first = first;
                 else if (m.kind == K_COMB_B || m.kind == K_COMB_B2) s_combines[idx].first = first;
                 else if (m.kind == K_ROW_B) s_rowlins[idx].first = first;
