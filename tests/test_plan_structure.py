@@ -32,6 +32,21 @@ def test_batched_plan_folds_the_clips_into_its_weight_gradient_gemms():
     assert all(m[4] == 0 for m in gemm_members(one, True))
 
 
+def test_batched_plan_runs_one_row_per_clip_linears_with_the_clips_as_rows():
+    # the style / song-info heads see ONE row per clip: on the 64x64 tiling an 11-clip plan carries them as GEMMs with M = 11
+    # (GemmDesc.clip_rows: one descriptor for all clips, weights read once) in forward and backward; the one-clip plan of the
+    # same shape has M = 1 there and no M = 11 anywhere (no layer width, channel, bar or beat count of this shape is 11)
+    native = sim_native()
+    dims = pc.make_dims(pc.FULL, 3, 2, 2, True)
+    dims.clips = 11
+    plan = nat.Plan(native, dims, 'cpu', gemm_tile=64)
+    for backward in (False, True):
+        rows11 = [m for m in gemm_members(plan, backward) if m[0] == 11 and m[4] == 0]
+        assert rows11, 'no clips-as-rows GEMM in the %s pass' % ('backward' if backward else 'forward')
+    one = nat.Plan(native, pc.make_dims(pc.FULL, 3, 2, 2, True), 'cpu', gemm_tile=64)
+    assert not [m for m in gemm_members(one, False) + gemm_members(one, True) if m[0] == 11]
+
+
 def step_rows(plan, backward, mask=7):
     import numpy as np
     n = plan.lib.mst_plan_step_count(plan.handle, mask, int(backward))
