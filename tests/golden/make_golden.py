@@ -6,7 +6,7 @@
 Imports the reference's `style.model` unmodified from /root/reference, drives
 it exactly like train-model.py:52-90,113-126,151-154 does (same construction
 order, seed, Adam/StepLR settings, positional get_total_loss call including the
-bpm-before-mode quirk) on the synthetic clips of oracle/synth.py, and stores
+bpm-before-mode quirk) on the synthetic clips of tools/synth.py, and stores
 inputs' seeds + expected outputs as .npz under tests/golden/.  The fixtures are
 data only; nothing of the reference's source travels.
 """
@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 import style.model as ref                    # the REFERENCE (PYTHONPATH=/root/reference)
-from oracle.synth import synth_clip, INSTRUMENT_SIZE, N_INSTRUMENTS
+from tools.synth import synth_clip, INSTRUMENT_SIZE, N_INSTRUMENTS
 
 assert os.path.realpath(ref.__file__).startswith('/root/reference/'), ref.__file__
 HERE = os.path.dirname(os.path.abspath(__file__))

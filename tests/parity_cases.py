@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle import style_oracle as so
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from simutil import GOLDEN, flat_from_named, make_dims, rel
 from style import _native as nat
 

@@ -19,7 +19,7 @@ def _worker(rank, world, port, out):
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from parity_cases import SMALL, set_clip
     from simutil import GOLDEN, flat_from_named, make_dims, sim_native
     from style import _native as nat
@@ -64,7 +64,7 @@ def _worker_batched(rank, world, port, out):
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from parity_cases import SMALL, random_params
     from simutil import make_dims, sim_native
     from style import _native as nat
@@ -114,7 +114,7 @@ def _tiled_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import parity_cases as pc
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from simutil import make_dims, sim_native
     from style import _native as nat
     native = sim_native()
@@ -143,7 +143,7 @@ def test_two_rank_bar_tiling_of_one_clip_equals_the_oracle(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import parity_cases as pc
     from oracle import style_oracle as so
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from simutil import make_dims, rel, sim_native
     from style import _native as nat
     native = sim_native()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from simutil import GOLDEN
 from test_gpu_model_surface import load_small, reference_call, to_dev
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import style_oracle as so
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from simutil import GOLDEN, rel
 from test_host_surface import FULL, SMALL, build_model
 

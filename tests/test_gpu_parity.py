@@ -107,7 +107,7 @@ def test_bar_tiling_two_tiles_bench_clip(native):
     # the bench clip's 16 bars over two "ranks" (both plans on this GPU, exchanges summed by hand)
     from test_tiled import run_tiled
     from oracle import style_oracle as so
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from simutil import make_dims, rel
     from style import _native as nat
     dev = torch.device('cuda:0')
@@ -130,7 +130,7 @@ def test_bar_tiling_config5_shape_eight_tiles(native):
     # eight plans on this one GPU stand in for the eight ranks
     from test_tiled import run_tiled
     from oracle import style_oracle as so
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from simutil import make_dims, rel
     dev = torch.device('cuda:0')
     C, R, T = 8, 151, 4

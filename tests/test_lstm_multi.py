@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import parity_cases as pc
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from simutil import sim_native
 from style import _native as nat
 

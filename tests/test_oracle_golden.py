@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import style_oracle as so
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 TOL = 2e-5      # rel-L2; oracle and reference run the same torch ops, so this is tight

@@ -10,7 +10,7 @@ import torch
 
 import parity_cases as pc
 from oracle import style_oracle as so
-from oracle.synth import synth_clip
+from tools.synth import synth_clip
 from simutil import make_dims, rel, sim_native
 from style import _native as nat
 

@@ -99,7 +99,7 @@ def test_lstm_exchange_timeout_surfaces_through_the_model(monkeypatch):
     (mst_plan_options.lstm_flavour = 2): every consumer runs into the 0.2 s timeout, ORs MST_DEV_LSTM_TIMEOUT into the plan's
     device status word and the launch drains; StyleTransferModel.check_device_status (what LossLog.flush calls) raises."""
     import time
-    from oracle.synth import synth_clip
+    from tools.synth import synth_clip
     from style import _native
     from style.train import build_model
     monkeypatch.setenv('MST_LSTM_FLAVOUR', '2')

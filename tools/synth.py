@@ -1,7 +1,7 @@
 """Deterministic synthetic piano-roll clips (TEST / BENCH INFRASTRUCTURE; SURVEY §8(d) input recipe).
 
 Lives outside oracle/ because bench.py's timed leg needs inputs too, and only its cpu_baseline leg may touch the oracle;
-oracle/synth.py re-exports it for the tests.
+the tests import it from here as well.
 
 No reference counterpart: the reference trains on the Lakh MIDI dataset, which
 cannot be shipped.  Shapes and feature order follow the reference's piano-roll
