@@ -45,22 +45,26 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const ConvDesc d, Bases 
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Bases b) {
-    constexpr int PA = 256 + 1, PB = 64 + 4;
+// WR = rows per wave: 64 (2 x 2 blocks per wave, 256-row tiles) or 32 (1 x 2 blocks, 128-row tiles).  The 128-row form has half the
+// operand reuse but twice the workgroups at ~2/3 of the registers: its workgroups fill the chip's slots in finer rounds (PMC: at
+// 64 clips the 1152 256-row workgroups ran a full round and a half-empty one on 768 slots).
+template <int WR>
+__global__ __launch_bounds__(256, WR == 64 ? 3 : 4) void conv_fwd_kernel(const ConvDesc d, Bases b) {
+    constexpr int BM = 4 * WR, NQ = (BM * 9 + 255) / 256, PA = BM + 1, PB = 64 + 4;
     __shared__ float As[CV_KT][PA];                                    // k-major window tile, transposing stores (odd pitch)
     __shared__ __attribute__((aligned(16))) float Bs[CV_KT][PB];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wv = MST_UNIFORM(tid >> 6);
     const int64_t rows_total = (int64_t)d.clips * d.P * NOCT;
-    const int64_t m0 = (int64_t)blockIdx.x * 256;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const cv_gp x = (cv_gp)b.p[SP_EXT0];
     const cv_gp wp = (cv_gp)(b.p[SP_TMP] + d.wp_off);
-    // item = tid + 256 q (q < 9) of the 256 rows x 9 groups: nine consecutive lanes walk one row's 144 bytes
-    unsigned xoff[9];            // element offset of the group at fraction 0, first half (window start may be negative: kept as int)
-    int e0[9], lds_a[9];
+    // item = tid + 256 q (q < NQ) of the BM rows x 9 groups: nine consecutive lanes walk one row's 144 bytes
+    unsigned xoff[NQ];            // element offset of the group at fraction 0, first half (window start may be negative: kept as int)
+    int e0[NQ], lds_a[NQ];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int item = tid + 256 * q, row = item / 9, g = item - row * 9;
+    for (int q = 0; q < NQ; ++q) {
+        const int item = min(tid + 256 * q, BM * 9 - 1), row = item / 9, g = item - row * 9;      // (NQ * 256 > BM * 9 at 128 rows: the surplus lanes repeat the last item)
         const int64_t m = m0 + row;
         const int64_t mm = m < rows_total ? m : rows_total - 1;
         const int64_t p = mm >> 3;
@@ -77,11 +81,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-    cv_f4 ra[9], rb[3];
+    cv_f4 ra[NQ], rb[3];
     auto issue = [&](const int kt) {
         const int f = kt >> 1, h = kt & 1;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             // Branch-free: ONE 16-byte load per group whatever its position.  The window offsets are 35 oct - 20 + 4 n, so a group
             // is wholly in front of the row (octave 0: conv padding), wholly inside, wholly behind it, or — octave 7 only — starts
             // at element 277 and has exactly its last element outside: that one is loaded one element early and shifted.
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
     for (int kt = 0; kt < CV_K / CV_KT; ++kt) {
         float* af = &As[0][0];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = e0[q] + CV_KT * (kt & 1);
             const bool part = e == CV_ROW - 3, ok = e >= 0 && e <= CV_ROW - 3;
             const cv_f4 t = ra[q];
@@ -123,19 +127,19 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_kernel(const ConvDesc d, Base
         }
         MST_LDS_BARRIER();
         if (kt + 1 < CV_K / CV_KT) issue(kt + 1);                      // flies under this k-tile's 72 MFMAs per wave
-        mst_mfma_ktile_2x2<CV_KT>(As, Bs, wv * 64, 0, l31, kh, acc);
+        mst_mfma_ktile_2x2<CV_KT, WR == 64, true>(As, Bs, wv * WR, 0, l31, kh, acc);
         MST_LDS_BARRIER();                                              // single LDS buffer: everyone is done reading before the next stores
     }
     // epilogue: x1[clip][p][oc * 8 + oct] = leaky(acc + bias[oc]).  A lane's 32 rows are 8 positions x 4 octaves: one division
     const float* bias = b.p[SP_PAR] + d.b_off;
     float* ws = b.p[SP_WS];
-    const unsigned pbase = (unsigned)(m0 >> 3) + (unsigned)wv * 8u;
+    const unsigned pbase = (unsigned)(m0 >> 3) + (unsigned)wv * (unsigned)(WR / 8);
     unsigned clip = pbase / (unsigned)d.P, pl = pbase - clip * (unsigned)d.P;
     float bn[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) bn[c] = (32 * c + l31) < d.OC ? bias[32 * c + l31] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {                                       // position pbase + t: accumulator block a = t >> 2, registers 4 (t & 3) ..
+    for (int t = 0; t < WR / 8; ++t) {                                       // position pbase + t: accumulator block a = t >> 2, registers 4 (t & 3) ..
         const int a = t >> 2;
         const int64_t pg = (int64_t)pbase + t;
         if (pg * NOCT < rows_total) {
@@ -286,7 +290,9 @@ int launch_conv_prep(const ConvDesc& d, Bases b, hipStream_t s) {
 }
 int launch_conv_fwd(const ConvDesc& d, Bases b, hipStream_t s) {
     const int64_t rows = (int64_t)d.clips * d.P * NOCT;
-    hipLaunchKernelGGL(conv_fwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d, b);
+    // 128-row tiles while the 256-row grid would not fill four rounds of the chip's 768 co-resident slots
+    if ((rows + 255) / 256 < 4 * 768) hipLaunchKernelGGL(conv_fwd_kernel<32>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, d, b);
+    else hipLaunchKernelGGL(conv_fwd_kernel<64>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d, b);
     return (int)hipGetLastError();
 }
 int launch_conv_dw(const ConvDesc& d, Bases b, hipStream_t s) {
